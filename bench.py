@@ -1,0 +1,213 @@
+#!/usr/bin/env python
+"""Headline benchmark: denoiser-forward throughput of ZigMa on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+metric  (BASELINE.json): denoiser-forward latents/sec = B*L tokens per second of ZigMa.forward,
+        ZigMa E=640, depth=18, L=32x32, zigzagN8 — workload = BASELINE configs[1]: the README model
+        (in_ch=3, img 32, has_text with 77x768 context) in bf16 at B=64 per GPU, synthetic x / t / y.
+step    = one ZigMa.forward over the per-rank batch (inputs resident in HBM before the timed region).
+N > 1   = batch-sharded replicas (weak scaling: B=64 per rank); the path has no collective inside the
+          forward — ranks only meet at the timing barriers and at the final all_gather of the velocities
+          (the analogue of accelerator.gather in sample_acc.py:435), which is inside the timed region.
+roofline  : the fused zigzag selective-scan kernel, timed with HIP events around every launch of it
+            inside the timed steps; achieved = algorithmic bytes / mean launch time.
+cpu_baseline : the numpy oracle (oracle/zigma_oracle.py, a port of the reference's pure-torch path) run on the
+            host cores on a bounded sample (one forward of the same model at B=2), rank 0, N=1 only.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK = 8.0e12        # B/s, MI355X HBM3E spec (MI355X_MICROARCH.md)
+
+WORKLOADS = {
+    # BASELINE configs[1]: README model, bf16, B=64 on one MI355X
+    "readme_text_b64": dict(model=dict(in_channels=3, img_dim=32, embed_dim=640, depth=18, patch_size=1, has_text=True,
+                                       d_context=768, n_context_token=77, scan_type="zigzagN8", use_pe=2),
+                            batch=64, x=(3, 32, 32), y=("text", 77, 768)),
+}
+
+
+class ScanTimer:
+    """HIP-event pairs around every scan launch (events are recorded on the stream the kernel goes to)."""
+
+    def __init__(self):
+        self.pairs = []
+        self.enabled = False
+
+    def install(self):
+        from zigma_amd import selective_scan_interface as ssi
+        raw = ssi.scan_raw
+        timer = self
+
+        def timed(*a, **k):
+            if not timer.enabled:
+                return raw(*a, **k)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            r = raw(*a, **k)
+            e1.record()
+            timer.pairs.append((e0, e1))
+            return r
+        ssi.scan_raw = timed
+
+    def mean_ms(self):
+        return sum(a.elapsed_time(b) for a, b in self.pairs) / max(len(self.pairs), 1)
+
+
+def build_model(cfg, device, dtype, seed=0):
+    from zigma_amd.model_zigma import ZigMa
+    torch.manual_seed(seed)
+    m = ZigMa(device=device, dtype=dtype, **cfg).eval()
+    g = torch.Generator(device="cpu").manual_seed(seed + 1)
+    with torch.no_grad():       # default init zeroes every adaLN gate; use O(1) gates so the mixers matter
+        for blk in m.blocks:
+            w, b = blk.adaLN_modulation[-1].weight, blk.adaLN_modulation[-1].bias
+            w.copy_((torch.randn(w.shape, generator=g) * 0.02).to(w))
+            b.copy_((torch.randn(b.shape, generator=g) * 0.5).to(b))
+        if hasattr(m, "pos_embed"):
+            m.pos_embed.copy_((torch.randn(m.pos_embed.shape, generator=g) * 0.02).to(m.pos_embed))
+    return m
+
+
+def make_inputs(wl, batch, device, seed):
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    x = torch.randn((batch,) + wl["x"], generator=g).to(device)
+    t = torch.rand(batch, generator=g).to(device)
+    y = torch.rand((batch,) + wl["y"][1:], generator=g).to(device=device, dtype=torch.bfloat16)
+    return x, t, y
+
+
+def cpu_baseline(wl, seed=0):
+    """Oracle forward (numpy, fp32) of the same architecture at B=2 on the host cores."""
+    import numpy as np
+    from oracle import zigma_oracle as zo
+    try:
+        from threadpoolctl import threadpool_info
+        threads = max([p.get("num_threads", 1) for p in threadpool_info()] + [1])
+    except Exception:
+        threads = os.cpu_count() or 1
+    from zigma_amd.model_zigma import ZigMa
+    torch.manual_seed(seed)
+    m = ZigMa(device="cpu", dtype=torch.float32, **wl["model"])
+    state = {k: v.detach().numpy() for k, v in m.state_dict().items()}
+    rng = np.random.default_rng(seed)
+    for k in state:                     # non-zero gates, as on the GPU side
+        if "adaLN_modulation.1.bias" in k:
+            state[k] = (rng.standard_normal(state[k].shape) * 0.5).astype(np.float32)
+    om = zo.ZigMaOracle(state, wl["model"])
+    B = 2
+    x = rng.standard_normal((B,) + wl["x"]).astype(np.float32)
+    t = rng.random(B).astype(np.float32)
+    y = rng.random((B,) + wl["y"][1:]).astype(np.float32)
+    t0 = time.perf_counter()
+    om.forward(x, t, y)
+    dt = time.perf_counter() - t0
+    L = (wl["model"]["img_dim"] // wl["model"]["patch_size"]) ** 2
+    return dict(value=B * L / dt, unit="tokens/s", cores=threads, kind="port",
+                sample=f"1 forward of the same model (E=640, depth=18, has_text) at B={B}, fp32 numpy oracle, {dt:.1f} s")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workload", default="readme_text_b64")
+    ap.add_argument("--batch", type=int, default=None, help="per-GPU batch (default: the workload's)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-scan-events", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    local_rank = int(os.environ.get("LOCAL_RANK", 0))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+
+    wl = WORKLOADS[args.workload]
+    batch = args.batch or wl["batch"]
+    model = build_model(wl["model"], device, torch.bfloat16)
+    x, t, y = make_inputs(wl, batch, device, seed=1234 + rank)      # per-rank seed, sample_acc.py:58
+    L = (wl["model"]["img_dim"] // wl["model"]["patch_size"]) ** 2
+    gathered = torch.empty((world * batch,) + wl["x"], device=device) if world > 1 else None
+
+    timer = ScanTimer()
+    timer.install()
+
+    def step():
+        with torch.no_grad():
+            v = model(x, t, y)
+        if world > 1:
+            dist.all_gather_into_tensor(gathered, v.contiguous())
+        return v
+
+    for _ in range(args.warmup):
+        step()
+    timer.enabled = not args.no_scan_events
+
+    def fence():
+        torch.cuda.synchronize(device)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(device)
+
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    timer.enabled = False
+    el = torch.tensor([elapsed], device=device, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(el, op=dist.ReduceOp.MAX)
+    elapsed = float(el.item())
+
+    if rank == 0:
+        from zigma_amd import _lib
+        Di, N = 2 * wl["model"]["embed_dim"], 16
+        algo_bytes = batch * L * (4 * 2 * Di + 2 * 2 * N) + 4 * Di * (N + 2)
+        roof = None
+        if timer.pairs:
+            ms = timer.mean_ms()
+            ach = algo_bytes / (ms * 1e-3)
+            roof = dict(bound="hbm", kernel="scan_tok (fused zigzag selective scan)", achieved=ach / 1e9,
+                        peak=HBM_PEAK / 1e9, unit="GB/s", frac=ach / HBM_PEAK, traffic=None,
+                        launch_us=ms * 1e3, launches=len(timer.pairs), algorithmic_bytes=algo_bytes)
+        line = dict(metric="denoiser-forward latents/sec (BxL tokens/s), ZigMa d=640 L=32^2",
+                    value=world * batch * L * args.steps / elapsed, unit="tokens/s", n_gpus=world, steps=args.steps,
+                    warmup=args.warmup, ms_per_step=elapsed / args.steps * 1e3, higher_is_better=True, scaling="weak",
+                    vs_baseline=None, dtype="bf16", data="synthetic",
+                    config=dict(workload=f"{args.workload}: ZigMa(in_ch=3,img=32,E=640,depth=18,zigzagN8,has_text 77x768), "
+                                         f"B={batch}/GPU, bf16, one forward per step",
+                                global_batch=world * batch, seq_len=L, parallelism=f"batch-sharded x{world}"),
+                    roofline=roof)
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(wl)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

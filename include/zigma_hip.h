@@ -1,0 +1,172 @@
+/*
+ * zigma_hip.h — C ABI of libzigma_hip.so, the MI355X (gfx950) native kernels behind the
+ * ZigMa denoiser-forward / ODE-sampling hot path.
+ *
+ * Drop-in boundary.  Each entry point replaces one native entry of the
+ * reference (CompVis/zigma); the parameter blocks mirror the PODs the reference already hands to
+ * its CUDA kernels, widened so that token-major (channel-contiguous) layouts and the zigzag row
+ * tables can be expressed without a separate index_select pass.
+ *
+ * Conventions (all entry points):
+ *   - plain pointers and sizes only; every pointer is a DEVICE pointer on the current device;
+ *   - the caller owns all memory and allocates the outputs; the library never allocates,
+ *     never synchronises, keeps no global state and is re-entrant;
+ *   - `stream` is a hipStream_t passed as void*; one call = one or more kernel launches on it;
+ *   - strides are in ELEMENTS of the tensor's own dtype;
+ *   - returns ZIGMA_OK (0) or a negative zigma_status_t; zigma_strerror() names it.  The Python
+ *     shim turns a non-zero status into RuntimeError, as TORCH_CHECK does in the reference.
+ */
+#ifndef ZIGMA_HIP_H_
+#define ZIGMA_HIP_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ZIGMA_ABI_VERSION 1
+
+typedef enum zigma_status {
+    ZIGMA_OK = 0,
+    ZIGMA_ERR_NULL = -1,        /* required pointer is NULL                                  */
+    ZIGMA_ERR_SHAPE = -2,       /* size out of the supported range                           */
+    ZIGMA_ERR_DTYPE = -3,       /* unsupported element type                                  */
+    ZIGMA_ERR_STRIDE = -4,      /* layout not supported by any kernel                        */
+    ZIGMA_ERR_LAUNCH = -5,      /* hipLaunchKernel / hipGetLastError failed                  */
+    ZIGMA_ERR_UNSUPPORTED = -6  /* feature of the reference that is out of scope (complex A) */
+} zigma_status_t;
+
+typedef enum zigma_dtype { ZIGMA_F32 = 0, ZIGMA_F16 = 1, ZIGMA_BF16 = 2 } zigma_dtype_t;
+
+/* ------------------------------------------------------------------------------------------
+ * Selective scan forward.
+ * Replaces  selective_scan_cuda.fwd  (reference dis_mamba/csrc/selective_scan/selective_scan.cpp:226-336,
+ * kernel selective_scan_fwd_kernel.cuh:67-303); parameter block mirrors SSMParamsBase
+ * (selective_scan.h:26-69).  Real A only (the reference's complex variant is never reached by ZigMa,
+ * mamba_simple.py:298).
+ *
+ *   delta' = delta + delta_bias[d];  if delta_softplus: delta' = delta' <= 20 ? log1p(exp(delta')) : delta'
+ *   h_n[l] = exp(delta'[l] * A[d,n]) * h_n[l-1] + delta'[l] * B[n,l] * u[l]
+ *   out[l] = sum_n C[n,l] * h_n[l] + D[d] * u[l];      out_z[l] = out[l] * z[l] / (1 + exp(-z[l]))
+ *
+ * u, delta, z, out, out_z are logically (batch, dim, seqlen) with arbitrary batch/d/l strides:
+ *   reference layout  = l_stride 1 (the reference REQUIRES this, selective_scan.cpp:252-253);
+ *   token-major layout = d_stride 1, l_stride = row pitch (what the fused ZigMa block uses).
+ * Variable B/C are (batch, n_groups, dstate, seqlen); constant B/C are (dim, dstate) float32.
+ * x receives the running prefix at every `chunk_len` boundary, (batch, dim, n_chunks, 2*dstate) f32,
+ * contiguous: x[b,d,c,2n] = prod_{l<=end(c)} exp(delta' A), x[b,d,c,2n+1] = h_n[end(c)]
+ * (selective_scan_fwd_kernel.cuh:251-254); last_state = x[:, :, -1, 1::2].  May be NULL.
+ *
+ * z_row_index / out_row_index (optional, int32[seqlen]) fuse the zigzag reordering of
+ * mamba_simple.py:55-61,362-395 into the kernel's own loads/stores: scan position k reads its gate
+ * from row z_row_index[k] of z and writes out/out_z to row out_row_index[k].
+ * ------------------------------------------------------------------------------------------ */
+typedef struct zigma_scan_params {
+    int32_t batch, dim, seqlen, dstate, n_groups;
+    int32_t is_variable_B, is_variable_C, delta_softplus;
+    int32_t io_dtype;   /* zigma_dtype_t of u, delta, z, out, out_z                                */
+    int32_t bc_dtype;   /* zigma_dtype_t of VARIABLE B / C (reference: == io_dtype)               */
+    int32_t chunk_len;  /* carry spacing for x; 0 -> 2048 (reference: selective_scan.cpp:307)      */
+    int32_t flags;      /* reserved, must be 0                                                      */
+
+    int64_t u_batch_stride, u_d_stride, u_l_stride;
+    int64_t delta_batch_stride, delta_d_stride, delta_l_stride;
+    int64_t z_batch_stride, z_d_stride, z_l_stride;
+    int64_t out_batch_stride, out_d_stride, out_l_stride;
+    int64_t out_z_batch_stride, out_z_d_stride, out_z_l_stride;
+    int64_t A_d_stride, A_dstate_stride;
+    int64_t B_batch_stride, B_group_stride, B_d_stride, B_dstate_stride, B_l_stride;
+    int64_t C_batch_stride, C_group_stride, C_d_stride, C_dstate_stride, C_l_stride;
+
+    const void *u, *delta, *A, *B, *C;
+    const void *D;           /* float32 (dim) or NULL  */
+    const void *delta_bias;  /* float32 (dim) or NULL  */
+    const void *z;           /* or NULL: no gating      */
+    void *out;               /* ungated y; may be NULL when z != NULL (only backward needs it)     */
+    void *out_z;             /* required iff z != NULL  */
+    void *x;                 /* float32 or NULL         */
+    const int32_t *z_row_index;
+    const int32_t *out_row_index;
+} zigma_scan_params_t;
+
+int zigma_selective_scan_fwd(const zigma_scan_params_t *p, void *stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Depthwise causal conv1d (+ bias, + SiLU) forward.
+ * Replaces  causal_conv1d_cuda.causal_conv1d_fwd  (reference dis_causal_conv1d/csrc/causal_conv1d.cpp:130-189,
+ * kernels causal_conv1d_fwd.cu:39-130,193-298); parameter block mirrors ConvParamsBase
+ * (causal_conv1d.h:9-35).
+ *
+ *   out[b,c,l] = act( bias[c] + sum_{w<width} weight[c,w] * x[b,c,l-(width-1-w)] ),  x[<0] = 0
+ *
+ * x/out logically (batch, dim, seqlen), arbitrary strides (channel-first, channel-last, views).
+ * x_row_index (optional, int32[seqlen]): the conv runs over the REORDERED sequence
+ * x'[k] = x[x_row_index[k]]  (zigzag gather of mamba_simple.py:362-370 fused into the loads).
+ * ------------------------------------------------------------------------------------------ */
+typedef struct zigma_conv_params {
+    int32_t batch, dim, seqlen, width;
+    int32_t silu_activation;
+    int32_t io_dtype;  /* x, out */
+    int32_t w_dtype;   /* weight, bias */
+    int32_t flags;     /* reserved, must be 0 */
+    int64_t x_batch_stride, x_c_stride, x_l_stride;
+    int64_t weight_c_stride, weight_width_stride;
+    int64_t out_batch_stride, out_c_stride, out_l_stride;
+    const void *x, *weight;
+    const void *bias;  /* or NULL */
+    void *out;
+    const int32_t *x_row_index;
+} zigma_conv_params_t;
+
+int zigma_causal_conv1d_fwd(const zigma_conv_params_t *p, void *stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Fused (gated-branch add) + residual add + RMSNorm / LayerNorm (+ adaLN modulate) forward.
+ * Replaces the Triton kernel `_layer_norm_fwd_1pass_kernel` and its host `_layer_norm_fwd`
+ * (reference dis_mamba/mamba_ssm/ops/triton/layernorm.py:65-120,123-177) and, when the optional
+ * pointers are given, the elementwise glue of Block.forward around it (model_zigma.py:53-54,388-460).
+ *
+ * Per row r (batch index b = r / rows_per_batch):
+ *   xe  = x[r]  (+ gate[b] * branch[r]          if branch != NULL;  xe is stored to x_out if != NULL)
+ *   res = xe (+ residual[r]);  residual_out[r] = res            (float statistics, layernorm.py:98-105)
+ *   y   = is_rms ? res * rsqrt(mean(res^2) + eps) : (res - mean) * rsqrt(var + eps)
+ *   y   = y * weight (+ bias)                                   (weight/bias may be NULL)
+ *   y_out[r] = y                                                (if y_out != NULL)
+ *   y_mod[r] = y * (1 + scale[b]) + shift[b]                    (if y_mod != NULL)   modulate()
+ * x, branch, x_out, y_out, y_mod share x_dtype; residual/residual_out have res_dtype; weight/bias
+ * w_dtype; gate/shift/scale are (batch, cols) rows of mod_dtype with pitch mod_batch_stride.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct zigma_norm_params {
+    int32_t rows, cols, rows_per_batch;
+    int32_t is_rms;
+    int32_t x_dtype, res_dtype, w_dtype, mod_dtype;
+    float eps;
+    int32_t flags;  /* reserved, must be 0 */
+    int64_t x_row_stride, branch_row_stride, x_out_row_stride;
+    int64_t res_row_stride, res_out_row_stride;
+    int64_t y_row_stride, y_mod_row_stride;
+    int64_t mod_batch_stride;
+    const void *x;
+    const void *branch, *gate;  /* both or neither */
+    void *x_out;
+    const void *residual;       /* or NULL */
+    void *residual_out;         /* or NULL */
+    const void *weight, *bias;  /* or NULL */
+    void *y_out;                /* or NULL */
+    const void *shift, *scale;  /* both or neither */
+    void *y_mod;                /* required iff shift != NULL */
+} zigma_norm_params_t;
+
+int zigma_add_norm_fwd(const zigma_norm_params_t *p, void *stream);
+
+/* ------------------------------------------------------------------------------------------ */
+const char *zigma_strerror(int status);
+int zigma_abi_version(void);
+/* Name of the kernel variant the last dispatch on this thread selected (for tests / profiling). */
+const char *zigma_last_kernel(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ZIGMA_HIP_H_ */

@@ -1,0 +1,172 @@
+"""CPU tests of the host side: C-ABI surface, struct layout, scan-order tables, module/state_dict
+compatibility, transport logic, and the no-fallback rule.  No GPU, no compute calls into the library."""
+import ast
+import ctypes
+import os
+import re
+import subprocess
+import tempfile
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import ROOT, load_golden, rel_err
+from oracle import zigma_oracle as zo
+
+
+@pytest.fixture(scope="module")
+def libpath():
+    from zigma_amd import _lib, build
+    if not os.path.exists(_lib.LIB_PATH):
+        build.build(verbose=False)
+    return _lib.LIB_PATH
+
+
+def test_cabi_exports_every_declared_symbol(libpath):
+    hdr = open(os.path.join(ROOT, "include", "zigma_hip.h")).read()
+    declared = set(re.findall(r"\b(zigma_[a-z0-9_]+)\s*\(", hdr))
+    assert {"zigma_selective_scan_fwd", "zigma_causal_conv1d_fwd", "zigma_add_norm_fwd"} <= declared
+    L = ctypes.CDLL(libpath)
+    for name in declared:
+        assert hasattr(L, name), name
+    L.zigma_abi_version.restype = ctypes.c_int
+    L.zigma_strerror.restype = ctypes.c_char_p
+    assert L.zigma_abi_version() == 1
+    assert L.zigma_strerror(-2) == b"size out of the supported range"
+    from zigma_amd import _lib
+    assert set(_lib.EXPORTS) <= declared
+
+
+def test_ctypes_structs_match_the_header():
+    """sizeof/offsetof of every field, as gcc sees include/zigma_hip.h, equal the ctypes mirror."""
+    from zigma_amd import _lib
+    structs = {"zigma_scan_params_t": _lib.ScanParams, "zigma_conv_params_t": _lib.ConvParams,
+               "zigma_norm_params_t": _lib.NormParams}
+    lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "zigma_hip.h"', "int main(void){"]
+    for cname, st in structs.items():
+        lines.append(f'printf("{cname} %zu\\n", sizeof({cname}));')
+        for f, _ in st._fields_:
+            lines.append(f'printf("{cname}.{f} %zu\\n", offsetof({cname}, {f}));')
+    lines.append("return 0;}")
+    with tempfile.TemporaryDirectory() as d:
+        src, exe = os.path.join(d, "a.c"), os.path.join(d, "a.out")
+        open(src, "w").write("\n".join(lines))
+        subprocess.run(["gcc", "-I", os.path.join(ROOT, "include"), src, "-o", exe], check=True)
+        out = subprocess.run([exe], check=True, capture_output=True, text=True).stdout
+    got = dict(l.split() for l in out.strip().splitlines())
+    for cname, st in structs.items():
+        assert int(got[cname]) == ctypes.sizeof(st), cname
+        for f, _ in st._fields_:
+            assert int(got[f"{cname}.{f}"]) == getattr(st, f).offset, (cname, f)
+
+
+def test_scan_paths_bit_exact_vs_reference_tables():
+    from zigma_amd import scan_paths as sp
+    g = load_golden("paths.npz")
+    for n in (4, 8, 16, 32):
+        zz, hh = sp.zigzag_path(n), sp.hilbert_path(n)
+        assert len(zz) == 8 and len(hh) == 8
+        for i in range(8):
+            assert zz[i].dtype == np.int64 and np.array_equal(zz[i], g[f"zigzag_{n}_{i}"])
+            assert np.array_equal(sp.reverse_permut_np(zz[i]), g[f"zigzag_rev_{n}_{i}"])
+            assert np.array_equal(hh[i], g[f"hilbert_{n}_{i}"])
+    for a, b in zip(sp.hilbert_path(128), zo.hilbert_paths(128)):
+        assert np.array_equal(a, b)
+    t = sp.to_device_tables(sp.zigzag_path(4), "cpu")
+    assert t[0].dtype == torch.int32 and t[7].tolist() == [15, 11, 7, 3, 2, 6, 10, 14, 13, 9, 5, 1, 0, 4, 8, 12]
+
+
+@pytest.mark.parametrize("name", ["zigma_text_zigzag2", "zigma_uncond_zigzag8", "zigma_class_v2", "zigma_hilbert2",
+                                  "zigma_video_sst"])
+def test_state_dict_is_reference_compatible(name):
+    """same keys and shapes as the reference module built with the same constructor arguments"""
+    from zigma_amd.model_zigma import ZigMa
+    g = load_golden(name + ".npz")
+    cfg = ast.literal_eval(str(g["cfg"]))
+    m = ZigMa(device="cpu", **cfg)
+    ref = {k[3:]: v.shape for k, v in g.items() if k.startswith("sd.")}
+    mine = {k: tuple(v.shape) for k, v in m.state_dict().items()}
+    assert set(mine) == set(ref)
+    for k in ref:
+        assert mine[k] == tuple(ref[k]), k
+    m.load_state_dict({k[3:]: torch.from_numpy(v) for k, v in g.items() if k.startswith("sd.")}, strict=True)
+    # per-layer row tables follow the reference's layer -> table assignment
+    om = zo.ZigMaOracle({k[3:]: v for k, v in g.items() if k.startswith("sd.")}, cfg)
+    if om.paths is not None:
+        for i, blk in enumerate(m.blocks):
+            assert np.array_equal(blk.mixer._perm.numpy().astype(np.int64), om.paths[i]), i
+
+
+def test_constructor_surface_and_defaults():
+    from zigma_amd.model_zigma import ZigMa
+    m = ZigMa(in_channels=4, embed_dim=32, depth=2, img_dim=8, device="cpu")           # default scan_type v2
+    assert "blocks.0.mixer.A_b_log" in m.state_dict() and m.final_layer.linear.weight.shape == (4, 32)
+    assert all(float(b.adaLN_modulation[-1].weight.detach().abs().sum()) == 0 for b in m.blocks)   # adaLN-zero init
+    with pytest.raises(ValueError):
+        ZigMa(in_channels=4, embed_dim=32, depth=2, img_dim=8, device="cpu", scan_type="v1")
+    m = ZigMa(in_channels=4, embed_dim=32, depth=2, img_dim=8, device="cpu", scan_type="parallelN2")
+    with pytest.raises(NotImplementedError):
+        m.forward_with_cfg(None, None, None, 1.0)
+
+
+def test_no_cpu_fallback():
+    """the product path refuses CPU tensors instead of silently computing somewhere else"""
+    from zigma_amd.causal_conv1d_interface import causal_conv1d_fn
+    from zigma_amd.layernorm import rms_norm_fn
+    from zigma_amd.selective_scan_interface import selective_scan_fn
+    u = torch.randn(1, 4, 8)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        selective_scan_fn(u, u, -torch.rand(4, 2), torch.randn(1, 2, 8), torch.randn(1, 2, 8))
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        causal_conv1d_fn(u, torch.randn(4, 4))
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        rms_norm_fn(u, torch.ones(8), None)
+    src = "".join(open(os.path.join(ROOT, "zigma_amd", f)).read() for f in os.listdir(os.path.join(ROOT, "zigma_amd"))
+                  if f.endswith(".py"))
+    assert "oracle" not in src.replace("the CPU oracle", "")      # product never imports the oracle
+
+
+def test_transport_rules_and_fixed_grid_solvers():
+    from zigma_amd.transport import ModelType, Sampler, create_transport
+    tr = create_transport()                                   # Linear / velocity
+    assert tr.model_type == ModelType.VELOCITY and tr.train_eps == 0 and tr.sample_eps == 0
+    assert tr.check_interval(0, 0, sde=False, eval=True) == (0, 1)
+    assert create_transport("Linear", "noise").train_eps == 1e-3
+    vp = create_transport("VP", "velocity")
+    assert vp.train_eps == 1e-5 and vp.check_interval(vp.train_eps, vp.sample_eps, eval=True)[1] == 1 - vp.sample_eps
+    with pytest.raises(ValueError):
+        create_transport(prediction="nope")
+    x0 = torch.tensor([[1.0, 2.0], [3.0, -4.0]], dtype=torch.float64)
+    model = lambda x, t: -x * (1 + t.view(-1, 1))
+    for method in ("euler", "midpoint", "heun2", "rk4"):
+        fn = Sampler(tr).sample_ode(sampling_method=method, num_steps=9)
+        got = fn(x0, model)
+        ref = zo.sample_ode_fixed(lambda x, t: -x * (1 + t[:, None]), x0.numpy(), num_steps=9,
+                                  method=method, dt=np.float64)
+        assert got.shape == (9, 2, 2) and rel_err(got.numpy(), ref) < 1e-6, method
+    exact = x0 * np.exp(-1.5)
+    for method, tol in (("dopri5", 1e-4), ("bosh3", 2e-3), ("adaptive_heun", 2e-2)):
+        got = Sampler(tr).sample_ode(sampling_method=method, num_steps=4, rtol=1e-5, atol=1e-8)(x0, model)
+        assert got.shape == (4, 2, 2) and rel_err(got[-1].numpy(), exact.numpy()) < tol, method
+    rev = Sampler(tr).sample_ode(sampling_method="euler", num_steps=3, reverse=True)(x0, lambda x, t: torch.ones_like(x))
+    assert torch.allclose(rev[-1], x0 - 1)                    # reverse integrates from t=1 down to 0
+    with pytest.raises(NotImplementedError):
+        Sampler(tr).sample_sde()
+
+
+def test_plans_match_closed_forms():
+    from zigma_amd.transport import path
+    t = torch.tensor([0.25, 0.5])
+    x0, x1 = torch.randn(2, 3), torch.randn(2, 3)
+    _, xt, ut = path.ICPlan().plan(t, x0, x1)
+    assert torch.allclose(xt, t[:, None] * x1 + (1 - t[:, None]) * x0) and torch.allclose(ut, x1 - x0)
+    g = path.GVPCPlan()
+    a, da = g.compute_alpha_t(t)
+    s, ds = g.compute_sigma_t(t)
+    assert torch.allclose(a ** 2 + s ** 2, torch.ones(2)) and torch.allclose(a * da + s * ds, torch.zeros(2), atol=1e-6)
+    # velocity -> score -> velocity round trip on the linear path
+    v = torch.randn(2, 3)
+    p = path.ICPlan()
+    sc = p.get_score_from_velocity(v, xt, t)
+    assert torch.allclose(p.get_velocity_from_score(sc, xt, t), v, atol=1e-4)

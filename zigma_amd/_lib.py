@@ -1,0 +1,127 @@
+"""ctypes binding of libzigma_hip.so (include/zigma_hip.h).
+
+The product path has NO fallback: if the shared library is missing or a kernel reports an error,
+the calling op raises.  torch is used for device memory and streams only — every pointer crossing
+the boundary is a raw device address (`Tensor.data_ptr()`), every launch goes to torch's current
+HIP stream so that stream semantics (and graph capture) match the reference's extensions
+(`at::cuda::getCurrentCUDAStream()`, selective_scan.cpp:326-327).
+"""
+import ctypes as C
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libzigma_hip.so")
+
+F32, F16, BF16 = 0, 1, 2
+_DT = {torch.float32: F32, torch.float16: F16, torch.bfloat16: BF16}
+
+i32, i64, vp, f32 = C.c_int32, C.c_int64, C.c_void_p, C.c_float
+
+
+class ScanParams(C.Structure):
+    _fields_ = (
+        [(n, i32) for n in ("batch", "dim", "seqlen", "dstate", "n_groups", "is_variable_B", "is_variable_C",
+                            "delta_softplus", "io_dtype", "bc_dtype", "chunk_len", "flags")]
+        + [(n, i64) for n in (
+            "u_batch_stride", "u_d_stride", "u_l_stride",
+            "delta_batch_stride", "delta_d_stride", "delta_l_stride",
+            "z_batch_stride", "z_d_stride", "z_l_stride",
+            "out_batch_stride", "out_d_stride", "out_l_stride",
+            "out_z_batch_stride", "out_z_d_stride", "out_z_l_stride",
+            "A_d_stride", "A_dstate_stride",
+            "B_batch_stride", "B_group_stride", "B_d_stride", "B_dstate_stride", "B_l_stride",
+            "C_batch_stride", "C_group_stride", "C_d_stride", "C_dstate_stride", "C_l_stride")]
+        + [(n, vp) for n in ("u", "delta", "A", "B", "C", "D", "delta_bias", "z", "out", "out_z", "x",
+                             "z_row_index", "out_row_index")]
+    )
+
+
+class ConvParams(C.Structure):
+    _fields_ = (
+        [(n, i32) for n in ("batch", "dim", "seqlen", "width", "silu_activation", "io_dtype", "w_dtype", "flags")]
+        + [(n, i64) for n in ("x_batch_stride", "x_c_stride", "x_l_stride", "weight_c_stride", "weight_width_stride",
+                              "out_batch_stride", "out_c_stride", "out_l_stride")]
+        + [(n, vp) for n in ("x", "weight", "bias", "out", "x_row_index")]
+    )
+
+
+class NormParams(C.Structure):
+    _fields_ = (
+        [(n, i32) for n in ("rows", "cols", "rows_per_batch", "is_rms", "x_dtype", "res_dtype", "w_dtype", "mod_dtype")]
+        + [("eps", f32), ("flags", i32)]
+        + [(n, i64) for n in ("x_row_stride", "branch_row_stride", "x_out_row_stride", "res_row_stride",
+                              "res_out_row_stride", "y_row_stride", "y_mod_row_stride", "mod_batch_stride")]
+        + [(n, vp) for n in ("x", "branch", "gate", "x_out", "residual", "residual_out", "weight", "bias", "y_out",
+                             "shift", "scale", "y_mod")]
+    )
+
+
+EXPORTS = ("zigma_selective_scan_fwd", "zigma_causal_conv1d_fwd", "zigma_add_norm_fwd", "zigma_strerror",
+           "zigma_abi_version", "zigma_last_kernel")
+
+_lib = None
+
+
+def lib():
+    """Load the shared library once; raise (never fall back) if it is not there."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"zigma_amd: {LIB_PATH} not built — run `python -m zigma_amd.build` (hipcc, gfx950). "
+                "There is no CPU or eager fallback for the HIP ops.")
+        L = C.CDLL(LIB_PATH)
+        for name, st in (("zigma_selective_scan_fwd", ScanParams), ("zigma_causal_conv1d_fwd", ConvParams),
+                         ("zigma_add_norm_fwd", NormParams)):
+            fn = getattr(L, name)
+            fn.argtypes = [C.POINTER(st), vp]
+            fn.restype = C.c_int
+        L.zigma_strerror.argtypes = [C.c_int]
+        L.zigma_strerror.restype = C.c_char_p
+        L.zigma_abi_version.restype = C.c_int
+        L.zigma_last_kernel.restype = C.c_char_p
+        if L.zigma_abi_version() != 1:
+            raise RuntimeError("zigma_amd: libzigma_hip.so ABI version mismatch")
+        _lib = L
+    return _lib
+
+
+def last_kernel():
+    return lib().zigma_last_kernel().decode()
+
+
+def dtype_id(t):
+    try:
+        return _DT[t.dtype]
+    except KeyError:
+        raise RuntimeError(f"zigma_amd: unsupported dtype {t.dtype}")
+
+
+def ptr(t):
+    return None if t is None else t.data_ptr()
+
+
+def require_device(*tensors):
+    dev = None
+    for t in tensors:
+        if t is None:
+            continue
+        if not t.is_cuda:
+            raise RuntimeError("zigma_amd: HIP kernels need tensors on a GPU device (no CPU fallback); got a "
+                               f"{t.device} tensor")
+        if dev is None:
+            dev = t.device
+        elif t.device != dev:
+            raise RuntimeError("zigma_amd: all tensors must be on the same device")
+    return dev
+
+
+def call(fn_name, params, device):
+    L = lib()
+    with torch.cuda.device(device):
+        stream = torch.cuda.current_stream(device).cuda_stream
+        rc = getattr(L, fn_name)(C.byref(params), C.c_void_p(stream))
+    if rc != 0:
+        raise RuntimeError(f"{fn_name}: {L.zigma_strerror(rc).decode()} (status {rc})")

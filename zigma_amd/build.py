@@ -1,0 +1,54 @@
+"""Build libzigma_hip.so (gfx950) in-tree with hipcc.  `python -m zigma_amd.build [--force]`."""
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+CSRC = os.path.join(HERE, "csrc")
+OBJ = os.path.join(HERE, "build")
+LIB = os.path.join(HERE, "lib", "libzigma_hip.so")
+SOURCES = ["api.hip", "selective_scan.hip", "causal_conv1d.hip", "add_norm.hip"]
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=fast", "-munsafe-fp-atomics",
+         "-I" + os.path.join(ROOT, "include"), "-I" + CSRC]
+
+
+def _stale(target, deps):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force=False, verbose=True, sources=None, lib=None, extra_flags=()):
+    sources = sources or SOURCES
+    lib = lib or LIB
+    os.makedirs(OBJ, exist_ok=True)
+    os.makedirs(os.path.dirname(lib), exist_ok=True)
+    headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
+    headers.append(os.path.join(ROOT, "include", "zigma_hip.h"))
+    jobs = []
+    objs = []
+    for src in sources:
+        s = os.path.join(CSRC, src)
+        o = os.path.join(OBJ, src.replace(".hip", ".o"))
+        objs.append(o)
+        if force or _stale(o, [s] + headers):
+            jobs.append([HIPCC, *FLAGS, *extra_flags, "-c", s, "-o", o])
+
+    def run(cmd):
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.run(cmd, check=True)
+
+    with ThreadPoolExecutor(max_workers=min(4, max(1, len(jobs)))) as ex:
+        list(ex.map(run, jobs))
+    if force or jobs or _stale(lib, objs):
+        run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", lib])
+    return lib
+
+
+if __name__ == "__main__":
+    build(force="--force" in sys.argv)

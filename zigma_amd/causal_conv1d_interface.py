@@ -1,0 +1,58 @@
+"""Depthwise causal conv1d op layer on the HIP kernel.
+
+Mirrors the reference's `dis_causal_conv1d/causal_conv1d/causal_conv1d_interface.py`:
+    causal_conv1d_fwd  <-> causal_conv1d_cuda.causal_conv1d_fwd   (causal_conv1d.cpp:130-189)
+    causal_conv1d_fn   <-> causal_conv1d_fn                       (causal_conv1d_interface.py:37-46)
+Forward only (bwd / update are later scope rows).
+"""
+import torch
+
+from . import _lib
+
+
+def causal_conv1d_raw(x, weight, bias, silu, *, out=None, x_row_index=None):
+    """x, out: logical (batch, dim, seqlen) views, any strides.  weight (dim, width), bias (dim,) or None."""
+    dev = _lib.require_device(x, weight, bias, out, x_row_index)
+    if x.dim() != 3:
+        raise RuntimeError("x must be (batch, dim, seqlen)")
+    batch, dim, L = x.shape
+    if weight.dim() != 2 or weight.shape[0] != dim:
+        raise RuntimeError("weight must be (dim, width)")
+    width = weight.shape[1]
+    if not 2 <= width <= 4:
+        raise RuntimeError("causal_conv1d only supports width between 2 and 4")
+    if bias is not None:
+        if bias.dtype != weight.dtype or bias.shape != (dim,):
+            raise RuntimeError("bias must be (dim,) with the dtype of weight")
+        if bias.stride(0) != 1:
+            bias = bias.contiguous()
+    if out is None:
+        out = torch.empty_like(x)
+    elif out.shape != x.shape or out.dtype != x.dtype:
+        raise RuntimeError("out must match x")
+    P = _lib.ConvParams()
+    P.batch, P.dim, P.seqlen, P.width = batch, dim, L, width
+    P.silu_activation = int(bool(silu))
+    P.io_dtype, P.w_dtype, P.flags = _lib.dtype_id(x), _lib.dtype_id(weight), 0
+    P.x_batch_stride, P.x_c_stride, P.x_l_stride = x.stride()
+    P.weight_c_stride, P.weight_width_stride = weight.stride()
+    P.out_batch_stride, P.out_c_stride, P.out_l_stride = out.stride()
+    P.x, P.weight, P.bias, P.out = _lib.ptr(x), _lib.ptr(weight), _lib.ptr(bias), _lib.ptr(out)
+    if x_row_index is not None:
+        if x_row_index.dtype != torch.int32 or x_row_index.shape != (L,) or not x_row_index.is_contiguous():
+            raise RuntimeError("x_row_index must be a contiguous int32 tensor of length seqlen")
+        P.x_row_index = _lib.ptr(x_row_index)
+    _lib.call("zigma_causal_conv1d_fwd", P, dev)
+    return out
+
+
+def causal_conv1d_fwd(x, weight, bias_, silu_activation):
+    """Drop-in for the extension entry `causal_conv1d_cuda.causal_conv1d_fwd(x, weight, bias, silu) -> out`."""
+    return causal_conv1d_raw(x, weight, bias_, silu_activation)
+
+
+def causal_conv1d_fn(x, weight, bias=None, activation=None):
+    """x: (batch, dim, seqlen); weight: (dim, width); bias: (dim,); activation: None | "silu" | "swish"."""
+    if activation not in [None, "silu", "swish"]:
+        raise NotImplementedError("activation must be None, silu, or swish")
+    return causal_conv1d_raw(x, weight, bias, activation in ["silu", "swish"])

@@ -1,0 +1,191 @@
+// Fused (gated-branch add) + residual add + RMSNorm/LayerNorm (+ adaLN modulate) forward, gfx950.
+// C ABI: zigma_add_norm_fwd (include/zigma_hip.h).
+//
+// Replaces the Triton kernel _layer_norm_fwd_1pass_kernel (reference dis_mamba/mamba_ssm/ops/triton/
+// layernorm.py:65-120) and folds in the elementwise glue Block.forward wraps around it
+// (model_zigma.py:53-54,441-458): the gate*branch residual of the previous sub-layer on the way in,
+// the adaLN modulate on the way out.  Pure HBM streaming: one wave owns one row, the row lives in
+// registers between the statistics and the normalisation, so every operand is read or written once.
+#include "zigma_common.h"
+
+namespace zigma {
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int s = 32; s > 0; s >>= 1) v += __shfl_xor(v, s, 64);
+    return v;
+}
+
+template <typename T> struct V4;  // 4 consecutive elements
+template <> struct V4<F32> { using type = uint4; };
+template <> struct V4<F16> { using type = uint2; };
+template <> struct V4<BF16> { using type = uint2; };
+
+template <typename T> __device__ __forceinline__ void load4(const void *base, int64_t idx, float (&f)[4]) {
+    if constexpr (T::id == ZIGMA_F32) {
+        const uint4 r = *reinterpret_cast<const uint4 *>(reinterpret_cast<const float *>(base) + idx);
+        f[0] = __uint_as_float(r.x); f[1] = __uint_as_float(r.y); f[2] = __uint_as_float(r.z); f[3] = __uint_as_float(r.w);
+    } else {
+        const uint2 r = *reinterpret_cast<const uint2 *>(reinterpret_cast<const uint16_t *>(base) + idx);
+        f[0] = to_float<T>(r.x & 0xffffu); f[1] = to_float<T>(r.x >> 16);
+        f[2] = to_float<T>(r.y & 0xffffu); f[3] = to_float<T>(r.y >> 16);
+    }
+}
+template <typename T> __device__ __forceinline__ void store4(void *base, int64_t idx, const float (&f)[4]) {
+    if constexpr (T::id == ZIGMA_F32) {
+        *reinterpret_cast<uint4 *>(reinterpret_cast<float *>(base) + idx) =
+            make_uint4(__float_as_uint(f[0]), __float_as_uint(f[1]), __float_as_uint(f[2]), __float_as_uint(f[3]));
+    } else {
+        *reinterpret_cast<uint2 *>(reinterpret_cast<uint16_t *>(base) + idx) =
+            make_uint2(from_float<T>(f[0]) | (uint32_t(from_float<T>(f[1])) << 16),
+                       from_float<T>(f[2]) | (uint32_t(from_float<T>(f[3])) << 16));
+    }
+}
+// value the tensor would hold after being stored in dtype T (the reference materialises these tensors)
+template <typename T> __device__ __forceinline__ float rnd(float v) { return to_float<T>(from_float<T>(v)); }
+
+// VEC = 4 (vector path) or 1 (scalar path, any alignment); ITERS chunks of 64*VEC columns per row.
+template <typename XT, typename RT, typename WT, typename MT, int VEC, int ITERS>
+__global__ __launch_bounds__(256) void add_norm_kernel(const zigma_norm_params_t p) {
+    const int lane = threadIdx.x & 63;
+    const int64_t r = static_cast<int64_t>(blockIdx.x) * 4 + (threadIdx.x >> 6);
+    if (r >= p.rows) return;
+    const int b = static_cast<int>(r / p.rows_per_batch);
+    const int cols = p.cols;
+
+    float v[ITERS][VEC];
+    float sum = 0.f, sq = 0.f;
+#pragma unroll
+    for (int it = 0; it < ITERS; ++it) {
+        const int c = (it * 64 + lane) * VEC;
+        if (c < cols) {
+            float x[VEC];
+            if constexpr (VEC == 4) load4<XT>(p.x, r * p.x_row_stride + c, x);
+            else x[0] = ld<XT>(p.x, r * p.x_row_stride + c);
+            if (p.branch) {
+                float br[VEC], g[VEC];
+                if constexpr (VEC == 4) { load4<XT>(p.branch, r * p.branch_row_stride + c, br); load4<MT>(p.gate, b * p.mod_batch_stride + c, g); }
+                else { br[0] = ld<XT>(p.branch, r * p.branch_row_stride + c); g[0] = ld<MT>(p.gate, b * p.mod_batch_stride + c); }
+#pragma unroll
+                for (int i = 0; i < VEC; ++i) x[i] = rnd<XT>(x[i] + g[i] * br[i]);
+                if (p.x_out) {
+                    if constexpr (VEC == 4) store4<XT>(p.x_out, r * p.x_out_row_stride + c, x);
+                    else st<XT>(p.x_out, r * p.x_out_row_stride + c, x[0]);
+                }
+            }
+            if (p.residual) {
+                float rs[VEC];
+                if constexpr (VEC == 4) load4<RT>(p.residual, r * p.res_row_stride + c, rs);
+                else rs[0] = ld<RT>(p.residual, r * p.res_row_stride + c);
+#pragma unroll
+                for (int i = 0; i < VEC; ++i) x[i] += rs[i];
+            }
+            if (p.residual_out) {
+                if constexpr (VEC == 4) store4<RT>(p.residual_out, r * p.res_out_row_stride + c, x);
+                else st<RT>(p.residual_out, r * p.res_out_row_stride + c, x[0]);
+            }
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) { v[it][i] = x[i]; sum += x[i]; sq += x[i] * x[i]; }
+        } else {
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) v[it][i] = 0.f;
+        }
+    }
+    float mean = 0.f, rstd;
+    if (p.is_rms) {
+        rstd = rsqrtf(wave_sum(sq) / cols + p.eps);
+    } else {  // two-pass variance on the register copy, like the Triton kernel (layernorm.py:102-107)
+        mean = wave_sum(sum) / cols;
+        float var = 0.f;
+#pragma unroll
+        for (int it = 0; it < ITERS; ++it) {
+            const int c = (it * 64 + lane) * VEC;
+            if (c < cols) {
+#pragma unroll
+                for (int i = 0; i < VEC; ++i) { const float dlt = v[it][i] - mean; var += dlt * dlt; }
+            }
+        }
+        rstd = rsqrtf(wave_sum(var) / cols + p.eps);
+    }
+#pragma unroll
+    for (int it = 0; it < ITERS; ++it) {
+        const int c = (it * 64 + lane) * VEC;
+        if (c < cols) {
+            float y[VEC], w[VEC], bs[VEC];
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) { w[i] = 1.f; bs[i] = 0.f; }
+            if (p.weight) { if constexpr (VEC == 4) load4<WT>(p.weight, c, w); else w[0] = ld<WT>(p.weight, c); }
+            if (p.bias) { if constexpr (VEC == 4) load4<WT>(p.bias, c, bs); else bs[0] = ld<WT>(p.bias, c); }
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) y[i] = (v[it][i] - mean) * rstd * w[i] + bs[i];
+            if (p.y_out) {
+                if constexpr (VEC == 4) store4<XT>(p.y_out, r * p.y_row_stride + c, y);
+                else st<XT>(p.y_out, r * p.y_row_stride + c, y[0]);
+            }
+            if (p.shift) {
+                float sh[VEC], sc[VEC];
+                if constexpr (VEC == 4) { load4<MT>(p.shift, b * p.mod_batch_stride + c, sh); load4<MT>(p.scale, b * p.mod_batch_stride + c, sc); }
+                else { sh[0] = ld<MT>(p.shift, b * p.mod_batch_stride + c); sc[0] = ld<MT>(p.scale, b * p.mod_batch_stride + c); }
+#pragma unroll
+                for (int i = 0; i < VEC; ++i) y[i] = rnd<XT>(y[i]) * (1.f + sc[i]) + sh[i];
+                if constexpr (VEC == 4) store4<XT>(p.y_mod, r * p.y_mod_row_stride + c, y);
+                else st<XT>(p.y_mod, r * p.y_mod_row_stride + c, y[0]);
+            }
+        }
+    }
+}
+
+static bool al(const void *ptr, size_t a) { return ptr == nullptr || reinterpret_cast<uintptr_t>(ptr) % a == 0; }
+
+template <typename XT, typename RT, typename WT, typename MT>
+static int launch_norm(const zigma_norm_params_t &p, hipStream_t stream) {
+    constexpr size_t xs = sizeof(typename XT::raw), rs = sizeof(typename RT::raw), ws = sizeof(typename WT::raw),
+                     ms = sizeof(typename MT::raw);
+    const bool vec = p.cols % 4 == 0 && p.x_row_stride % 4 == 0 && p.branch_row_stride % 4 == 0 && p.x_out_row_stride % 4 == 0 &&
+                     p.res_row_stride % 4 == 0 && p.res_out_row_stride % 4 == 0 && p.y_row_stride % 4 == 0 &&
+                     p.y_mod_row_stride % 4 == 0 && p.mod_batch_stride % 4 == 0 && al(p.x, 4 * xs) && al(p.branch, 4 * xs) &&
+                     al(p.x_out, 4 * xs) && al(p.y_out, 4 * xs) && al(p.y_mod, 4 * xs) && al(p.residual, 4 * rs) &&
+                     al(p.residual_out, 4 * rs) && al(p.weight, 4 * ws) && al(p.bias, 4 * ws) && al(p.gate, 4 * ms) &&
+                     al(p.shift, 4 * ms) && al(p.scale, 4 * ms);
+    dim3 grid(static_cast<unsigned>((static_cast<int64_t>(p.rows) + 3) / 4)), block(256);
+#define ZIGMA_NORM(V_, I_) hipLaunchKernelGGL((add_norm_kernel<XT, RT, WT, MT, V_, I_>), grid, block, 0, stream, p)
+    if (vec && p.cols <= 256 * 4) ZIGMA_NORM(4, 4);
+    else if (vec && p.cols <= 256 * 16) ZIGMA_NORM(4, 16);
+    else if (p.cols <= 64 * 16) ZIGMA_NORM(1, 16);
+    else if (p.cols <= 64 * 64) ZIGMA_NORM(1, 64);
+    else return ZIGMA_ERR_SHAPE;
+#undef ZIGMA_NORM
+    set_last_kernel(vec ? "add_norm_v4" : "add_norm_v1");
+    return check_launch();
+}
+
+}  // namespace zigma
+
+using namespace zigma;
+
+extern "C" int zigma_add_norm_fwd(const zigma_norm_params_t *pp, void *stream_) {
+    if (!pp) return ZIGMA_ERR_NULL;
+    const zigma_norm_params_t &p = *pp;
+    if (!p.x) return ZIGMA_ERR_NULL;
+    if ((p.branch == nullptr) != (p.gate == nullptr)) return ZIGMA_ERR_NULL;
+    if ((p.shift == nullptr) != (p.scale == nullptr)) return ZIGMA_ERR_NULL;
+    if (p.shift && !p.y_mod) return ZIGMA_ERR_NULL;
+    if (!p.y_out && !p.y_mod) return ZIGMA_ERR_NULL;
+    if (p.rows < 0 || p.cols < 1 || p.rows_per_batch < 1) return ZIGMA_ERR_SHAPE;
+    if (p.flags != 0) return ZIGMA_ERR_UNSUPPORTED;
+    if (p.rows == 0) return ZIGMA_OK;
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    // residual stream is f32 or the activation dtype; weights f32 or activation dtype; keep the
+    // instantiation set small: (x, res, w, mod) in {(T,F32|T,F32|T,T)}
+    ZIGMA_DISPATCH_DTYPE(p.x_dtype, XT, {
+        if (p.mod_dtype != p.x_dtype && (p.gate || p.shift)) return ZIGMA_ERR_DTYPE;
+        const bool res32 = p.res_dtype == ZIGMA_F32, w32 = p.w_dtype == ZIGMA_F32;
+        if (!res32 && p.res_dtype != p.x_dtype) return ZIGMA_ERR_DTYPE;
+        if (!w32 && p.w_dtype != p.x_dtype) return ZIGMA_ERR_DTYPE;
+        if (res32 && w32) return launch_norm<XT, F32, F32, XT>(p, stream);
+        if (res32) return launch_norm<XT, F32, XT, XT>(p, stream);
+        if (w32) return launch_norm<XT, XT, F32, XT>(p, stream);
+        return launch_norm<XT, XT, XT, XT>(p, stream);
+    })
+    return ZIGMA_ERR_DTYPE;
+}

@@ -1,0 +1,165 @@
+// Depthwise causal conv1d (+bias, +SiLU) forward for gfx950.  C ABI: zigma_causal_conv1d_fwd.
+//
+// Replaces causal_conv1d_fwd_kernel / causal_conv1d_channellast_fwd_kernel of the reference
+// (dis_causal_conv1d/csrc/causal_conv1d_fwd.cu:39-130,193-298).  HBM-bound (read x once, write out
+// once), so the only things that matter are full-line coalesced accesses and enough waves.
+//
+//  conv_tok_kernel     — token-major (channel contiguous) operands: a lane owns VEC adjacent channels
+//      (8-16 B per access), walks LT consecutive scan positions keeping the width-1 previous inputs
+//      in registers; the zigzag gather (x_row_index) picks whole rows, so it costs nothing.
+//  conv_generic_kernel — any strides (channel-first views of the reference, channel-last, ...): one
+//      output element per thread, threads run along the contiguous dimension.
+#include "zigma_common.h"
+
+namespace zigma {
+
+template <typename T, int VEC> struct Pack;
+template <> struct Pack<BF16, 4> { using type = uint2; };
+template <> struct Pack<F16, 4> { using type = uint2; };
+template <> struct Pack<F32, 4> { using type = uint4; };
+
+template <typename T> __device__ __forceinline__ void unpack4(const typename Pack<T, 4>::type &r, float (&f)[4]);
+template <> __device__ __forceinline__ void unpack4<BF16>(const uint2 &r, float (&f)[4]) {
+    f[0] = __uint_as_float(r.x << 16); f[1] = __uint_as_float(r.x & 0xffff0000u);
+    f[2] = __uint_as_float(r.y << 16); f[3] = __uint_as_float(r.y & 0xffff0000u);
+}
+template <> __device__ __forceinline__ void unpack4<F16>(const uint2 &r, float (&f)[4]) {
+    f[0] = to_float<F16>(r.x & 0xffffu); f[1] = to_float<F16>(r.x >> 16);
+    f[2] = to_float<F16>(r.y & 0xffffu); f[3] = to_float<F16>(r.y >> 16);
+}
+template <> __device__ __forceinline__ void unpack4<F32>(const uint4 &r, float (&f)[4]) {
+    f[0] = __uint_as_float(r.x); f[1] = __uint_as_float(r.y); f[2] = __uint_as_float(r.z); f[3] = __uint_as_float(r.w);
+}
+template <typename T> __device__ __forceinline__ typename Pack<T, 4>::type pack4(const float (&f)[4]);
+template <> __device__ __forceinline__ uint2 pack4<BF16>(const float (&f)[4]) {
+    return make_uint2(from_float<BF16>(f[0]) | (uint32_t(from_float<BF16>(f[1])) << 16),
+                      from_float<BF16>(f[2]) | (uint32_t(from_float<BF16>(f[3])) << 16));
+}
+template <> __device__ __forceinline__ uint2 pack4<F16>(const float (&f)[4]) {
+    return make_uint2(from_float<F16>(f[0]) | (uint32_t(from_float<F16>(f[1])) << 16),
+                      from_float<F16>(f[2]) | (uint32_t(from_float<F16>(f[3])) << 16));
+}
+template <> __device__ __forceinline__ uint4 pack4<F32>(const float (&f)[4]) {
+    return make_uint4(__float_as_uint(f[0]), __float_as_uint(f[1]), __float_as_uint(f[2]), __float_as_uint(f[3]));
+}
+
+// grid: (ceil(dim / (4*64)), ceil(L / LT), batch); block 64.
+template <typename IO, typename WT, int W, int LT, bool SILU>
+__global__ __launch_bounds__(64) void conv_tok_kernel(const zigma_conv_params_t p) {
+    using P = typename Pack<IO, 4>::type;
+    const int c0 = (blockIdx.x * 64 + threadIdx.x) * 4;
+    if (c0 >= p.dim) return;
+    const int b = blockIdx.z;
+    const int k0 = blockIdx.y * LT;
+    const int L = p.seqlen;
+
+    float w[4][W], bias[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+#pragma unroll
+        for (int j = 0; j < W; ++j) w[i][j] = ld<WT>(p.weight, (c0 + i) * p.weight_c_stride + j * p.weight_width_stride);
+        bias[i] = p.bias ? ld<WT>(p.bias, c0 + i) : 0.f;
+    }
+    const char *xb = reinterpret_cast<const char *>(p.x) + (b * p.x_batch_stride + c0) * sizeof(typename IO::raw);
+    char *ob = reinterpret_cast<char *>(p.out) + (b * p.out_batch_stride + c0) * sizeof(typename IO::raw);
+    const int64_t xls = p.x_l_stride * sizeof(typename IO::raw), ols = p.out_l_stride * sizeof(typename IO::raw);
+
+    auto row = [&](int k) -> P {  // scan position k (may be < 0: zero padding)
+        if (k < 0) return P{};
+        const int64_t r = p.x_row_index ? p.x_row_index[k] : k;
+        return *reinterpret_cast<const P *>(xb + r * xls);
+    };
+    float win[W][4];  // win[j] = x'[k - (W-1) + j]
+#pragma unroll
+    for (int j = 0; j < W - 1; ++j) unpack4<IO>(row(k0 - (W - 1) + j), win[j]);
+
+    const int kend = min(k0 + LT, L);
+#pragma unroll 4
+    for (int k = k0; k < kend; ++k) {
+        unpack4<IO>(row(k), win[W - 1]);
+        float o[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            float acc = bias[i];
+#pragma unroll
+            for (int j = 0; j < W; ++j) acc += w[i][j] * win[j][i];
+            o[i] = SILU ? silu(acc) : acc;
+        }
+        *reinterpret_cast<P *>(ob + k * ols) = pack4<IO>(o);
+#pragma unroll
+        for (int j = 0; j < W - 1; ++j)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) win[j][i] = win[j + 1][i];
+    }
+}
+
+// one output per thread; threads fastest along l when CONTIG_L, along c otherwise.
+template <typename IO, typename WT, bool CONTIG_L>
+__global__ __launch_bounds__(256) void conv_generic_kernel(const zigma_conv_params_t p) {
+    const int64_t idx = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
+    const int64_t per_b = static_cast<int64_t>(p.dim) * p.seqlen;
+    if (idx >= per_b * p.batch) return;
+    const int b = static_cast<int>(idx / per_b);
+    const int64_t rem = idx % per_b;
+    const int c = CONTIG_L ? static_cast<int>(rem / p.seqlen) : static_cast<int>(rem % p.dim);
+    const int l = CONTIG_L ? static_cast<int>(rem % p.seqlen) : static_cast<int>(rem / p.dim);
+    float acc = p.bias ? ld<WT>(p.bias, c) : 0.f;
+    const int64_t xo = b * p.x_batch_stride + c * p.x_c_stride;
+    for (int j = 0; j < p.width; ++j) {
+        const int k = l - (p.width - 1 - j);
+        if (k >= 0) {
+            const int64_t r = p.x_row_index ? p.x_row_index[k] : k;
+            acc += ld<WT>(p.weight, c * p.weight_c_stride + j * p.weight_width_stride) * ld<IO>(p.x, xo + r * p.x_l_stride);
+        }
+    }
+    if (p.silu_activation) acc = silu(acc);
+    st<IO>(p.out, b * p.out_batch_stride + c * p.out_c_stride + l * p.out_l_stride, acc);
+}
+
+template <typename IO, typename WT>
+static int launch_conv(const zigma_conv_params_t &p, hipStream_t stream) {
+    constexpr size_t es = sizeof(typename IO::raw);
+    const bool tok = p.x_c_stride == 1 && p.out_c_stride == 1 && p.dim % 4 == 0 &&
+                     reinterpret_cast<uintptr_t>(p.x) % (4 * es) == 0 && reinterpret_cast<uintptr_t>(p.out) % (4 * es) == 0 &&
+                     p.x_l_stride % 4 == 0 && p.out_l_stride % 4 == 0 && p.x_batch_stride % 4 == 0 && p.out_batch_stride % 4 == 0;
+    if (tok) {
+        constexpr int LT = 32;
+        dim3 grid((p.dim / 4 + 63) / 64, (p.seqlen + LT - 1) / LT, p.batch), block(64);
+#define ZIGMA_CONV_TOK(W_)                                                                                          \
+    if (p.silu_activation) hipLaunchKernelGGL((conv_tok_kernel<IO, WT, W_, LT, true>), grid, block, 0, stream, p);  \
+    else hipLaunchKernelGGL((conv_tok_kernel<IO, WT, W_, LT, false>), grid, block, 0, stream, p);
+        switch (p.width) {
+            case 2: ZIGMA_CONV_TOK(2) break;
+            case 3: ZIGMA_CONV_TOK(3) break;
+            default: ZIGMA_CONV_TOK(4) break;
+        }
+#undef ZIGMA_CONV_TOK
+        set_last_kernel("conv_tok");
+        return check_launch();
+    }
+    const int64_t total = static_cast<int64_t>(p.batch) * p.dim * p.seqlen;
+    dim3 grid(static_cast<unsigned>((total + 255) / 256)), block(256);
+    if (p.x_l_stride == 1) hipLaunchKernelGGL((conv_generic_kernel<IO, WT, true>), grid, block, 0, stream, p);
+    else hipLaunchKernelGGL((conv_generic_kernel<IO, WT, false>), grid, block, 0, stream, p);
+    set_last_kernel("conv_generic");
+    return check_launch();
+}
+
+}  // namespace zigma
+
+using namespace zigma;
+
+extern "C" int zigma_causal_conv1d_fwd(const zigma_conv_params_t *pp, void *stream_) {
+    if (!pp) return ZIGMA_ERR_NULL;
+    const zigma_conv_params_t &p = *pp;
+    if (!p.x || !p.weight || !p.out) return ZIGMA_ERR_NULL;
+    if (p.width < 2 || p.width > 4) return ZIGMA_ERR_SHAPE;  // causal_conv1d.cpp:157
+    if (p.batch < 0 || p.dim < 0 || p.seqlen < 0) return ZIGMA_ERR_SHAPE;
+    if (p.flags != 0) return ZIGMA_ERR_UNSUPPORTED;
+    if (p.batch == 0 || p.dim == 0 || p.seqlen == 0) return ZIGMA_OK;
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    ZIGMA_DISPATCH_DTYPE(p.io_dtype, IO, {
+        ZIGMA_DISPATCH_DTYPE(p.w_dtype, WT, { return launch_conv<IO, WT>(p, stream); })
+    })
+    return ZIGMA_ERR_DTYPE;
+}

@@ -1,0 +1,90 @@
+// Shared device/host helpers for libzigma_hip.so (gfx950 only; wave = 64).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "zigma_hip.h"
+
+namespace zigma {
+
+constexpr int kWave = 64;
+
+typedef float v2f __attribute__((ext_vector_type(2)));
+typedef float v4f __attribute__((ext_vector_type(4)));
+
+// ---- element types -----------------------------------------------------------------------------
+// I/O element wrappers: 16-bit types are carried as raw uint16_t and widened by bit ops (bf16) or
+// the hardware converter (f16); arithmetic is always float32.
+struct F32 { using raw = float;    static constexpr int id = ZIGMA_F32;  };
+struct F16 { using raw = uint16_t; static constexpr int id = ZIGMA_F16;  };
+struct BF16 { using raw = uint16_t; static constexpr int id = ZIGMA_BF16; };
+
+template <typename T> __device__ __forceinline__ float to_float(typename T::raw v);
+template <> __device__ __forceinline__ float to_float<F32>(float v) { return v; }
+template <> __device__ __forceinline__ float to_float<BF16>(uint16_t v) {
+    return __uint_as_float(static_cast<uint32_t>(v) << 16);
+}
+template <> __device__ __forceinline__ float to_float<F16>(uint16_t v) {
+    _Float16 h;
+    __builtin_memcpy(&h, &v, 2);
+    return static_cast<float>(h);
+}
+
+template <typename T> __device__ __forceinline__ typename T::raw from_float(float f);
+template <> __device__ __forceinline__ float from_float<F32>(float f) { return f; }
+template <> __device__ __forceinline__ uint16_t from_float<BF16>(float f) {
+    // round-to-nearest-even, NaN kept quiet (same as at::BFloat16)
+    uint32_t u = __float_as_uint(f);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return static_cast<uint16_t>((u >> 16) | 0x40u);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return static_cast<uint16_t>(u >> 16);
+}
+template <> __device__ __forceinline__ uint16_t from_float<F16>(float f) {
+    _Float16 h = static_cast<_Float16>(f);
+    uint16_t v;
+    __builtin_memcpy(&v, &h, 2);
+    return v;
+}
+
+template <typename T> __device__ __forceinline__ float ld(const void *base, int64_t idx) {
+    return to_float<T>(reinterpret_cast<const typename T::raw *>(base)[idx]);
+}
+template <typename T> __device__ __forceinline__ void st(void *base, int64_t idx, float v) {
+    reinterpret_cast<typename T::raw *>(base)[idx] = from_float<T>(v);
+}
+
+// ---- math (reference numerics: selective_scan_fwd_kernel.cuh:153-156,216,293) ------------------
+constexpr float kLog2e = 1.4426950408889634f;
+constexpr float kLn2 = 0.6931471805599453f;
+
+__device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }   // v_exp_f32
+__device__ __forceinline__ float fast_log2(float x) { return __builtin_amdgcn_logf(x); }    // v_log_f32
+__device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }     // v_rcp_f32
+
+// softplus with pass-through above 20 (reference: x <= 20 ? log1pf(expf(x)) : x).
+// log1p(t), t = e^x: short alternating series while t is small (keeps full relative accuracy for
+// very negative x, where 1+t would round t away), hardware log2 otherwise.
+__device__ __forceinline__ float softplus20(float x) {
+    const float t = fast_exp2(fminf(x, 20.f) * kLog2e);
+    const float series = t * (1.f + t * (-0.5f + t * (0.33333334f + t * (-0.25f + t * 0.2f))));
+    const float big = fast_log2(1.f + t) * kLn2;
+    const float sp = t < 0.0625f ? series : big;
+    return x > 20.f ? x : sp;
+}
+
+// x * sigmoid(x) written as z / (1 + exp(-z)) like the reference kernel.
+__device__ __forceinline__ float silu(float z) { return z * fast_rcp(1.f + fast_exp2(-z * kLog2e)); }
+
+// ---- host side -----------------------------------------------------------------------------------
+inline int check_launch() { return hipGetLastError() == hipSuccess ? ZIGMA_OK : ZIGMA_ERR_LAUNCH; }
+void set_last_kernel(const char *name);
+
+#define ZIGMA_DISPATCH_DTYPE(DT, T, ...)                                   \
+    switch (DT) {                                                          \
+        case ZIGMA_F32: { using T = ::zigma::F32; __VA_ARGS__; break; }    \
+        case ZIGMA_F16: { using T = ::zigma::F16; __VA_ARGS__; break; }    \
+        case ZIGMA_BF16: { using T = ::zigma::BF16; __VA_ARGS__; break; }  \
+        default: return ZIGMA_ERR_DTYPE;                                   \
+    }
+
+}  // namespace zigma

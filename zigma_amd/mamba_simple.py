@@ -1,0 +1,179 @@
+"""Mamba mixer with ZigMa's scan_type dispatch, on the token-major HIP path.
+
+Mirrors `Mamba` of the reference (dis_mamba/mamba_ssm/modules/mamba_simple.py:64-268 constructor,
+:274-444 forward): same constructor signature, same parameter names and shapes (state_dict compatible),
+same scan_type vocabulary.  The forward is re-designed for MI355X: activations stay (B, L, C) from the
+in_proj GEMM to the out_proj GEMM; the token reordering of every scan type (zigzag / Hilbert / random
+permutation, the reversed sweep of `v2`, the per-frame / per-pixel sequences of the video types) is a
+row-index table consumed by the conv and scan kernels, so no `index_select`, `flip`, `cat` or
+`rearrange(...).contiguous()` pass exists (reference :362-370, :320-337, :388-394).
+"""
+import math
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .selective_scan_interface import mamba_inner_tok
+
+
+def _int32_table(t, device):
+    if t is None:
+        return None
+    if not torch.is_tensor(t):
+        t = torch.as_tensor(t)
+    return t.to(device=device, dtype=torch.int32).contiguous()
+
+
+class Mamba(nn.Module):
+    def __init__(self, d_model, d_state=16, d_conv=4, expand=2, dt_rank="auto", dt_min=0.001, dt_max=0.1,
+                 dt_init="random", dt_scale=1.0, dt_init_floor=1e-4, conv_bias=True, bias=False,
+                 use_fast_path=True, layer_idx=None, device=None, dtype=None, scan_type="v2", **kwargs):
+        factory_kwargs = {"device": device, "dtype": dtype}
+        super().__init__()
+        self.d_model = d_model
+        self.d_state = d_state
+        self.d_conv = d_conv
+        self.expand = expand
+        self.d_inner = int(self.expand * self.d_model)
+        self.dt_rank = math.ceil(self.d_model / 16) if dt_rank == "auto" else dt_rank
+        self.use_fast_path = use_fast_path
+        self.layer_idx = layer_idx
+        if scan_type.startswith("zzvideo_"):   # the reference's ZigMa emits zzvideo_*, its Mamba only accepts video_*
+            scan_type = "video_" + scan_type[len("zzvideo_"):]
+        self.scan_type = scan_type
+
+        self.in_proj = nn.Linear(self.d_model, self.d_inner * 2, bias=bias, **factory_kwargs)
+        self.conv1d = nn.Conv1d(self.d_inner, self.d_inner, bias=conv_bias, kernel_size=d_conv, groups=self.d_inner,
+                                padding=d_conv - 1, **factory_kwargs)
+        self.zigzag_paths = kwargs.get("zigzag_paths", None)
+        self.zigzag_paths_reverse = kwargs.get("zigzag_paths_reverse", None)
+        self.video_frames = kwargs.get("video_frames", None)
+        self.st_order = kwargs.get("st_order", None)
+        self.extras = kwargs.get("extras", None)
+        self.use_jit = kwargs.get("use_jit", False)
+        self.activation = "silu"
+        self.act = nn.SiLU()
+
+        self.x_proj = nn.Linear(self.d_inner, self.dt_rank + self.d_state * 2, bias=False, **factory_kwargs)
+        self.dt_proj = nn.Linear(self.dt_rank, self.d_inner, bias=True, **factory_kwargs)
+        self._init_dt(self.dt_proj, dt_init, dt_scale, dt_min, dt_max, dt_init_floor, factory_kwargs)
+        self.A_log = nn.Parameter(self._s4d_real_log(device))
+        self.A_log._no_weight_decay = True
+        self.D = nn.Parameter(torch.ones(self.d_inner, device=device))
+        self.D._no_weight_decay = True
+
+        ok = (scan_type in ("v1", "v2") or scan_type.startswith(("video_", "zigzagN", "hilbertN", "randomN", "parallelN")))
+        assert ok, f"Invalid scan_type: {scan_type}"
+
+        if scan_type.startswith("parallelN"):
+            # constructor-compatible only: the reference builds these lists but has no forward branch for them
+            self.parallel_num = int(scan_type.replace("parallelN", ""))
+            A_list, conv_list, x_list, dt_list, D_list = [], [], [], [], []
+            for _ in range(self.parallel_num):
+                self.A_b_log = nn.Parameter(self._s4d_real_log(device))
+                self.A_b_log._no_weight_decay = True
+                A_list.append(self.A_b_log)
+                self.conv1d_b = nn.Conv1d(self.d_inner, self.d_inner, bias=conv_bias, kernel_size=d_conv,
+                                          groups=self.d_inner, padding=d_conv - 1, **factory_kwargs)
+                conv_list.append(self.conv1d_b)
+                self.x_proj_b = nn.Linear(self.d_inner, self.dt_rank + self.d_state * 2, bias=False, **factory_kwargs)
+                x_list.append(self.x_proj_b)
+                self.dt_proj_b = nn.Linear(self.dt_rank, self.d_inner, bias=True, **factory_kwargs)
+                dt_list.append(self.dt_proj_b)
+                self.D_b = nn.Parameter(torch.ones(self.d_inner, device=device))
+                self.D_b._no_weight_decay = True
+                D_list.append(self.D_b)
+            self.A_b_log_list = nn.ParameterList(A_list)
+            self.conv1d_b_list = nn.ModuleList(conv_list)
+            self.x_proj_b_list = nn.ModuleList(x_list)
+            self.dt_proj_b_list = nn.ModuleList(dt_list)
+            self.D_b_list = nn.ParameterList(D_list)
+        elif scan_type == "v2":
+            self.A_b_log = nn.Parameter(self._s4d_real_log(device))
+            self.A_b_log._no_weight_decay = True
+            self.conv1d_b = nn.Conv1d(self.d_inner, self.d_inner, bias=conv_bias, kernel_size=d_conv,
+                                      groups=self.d_inner, padding=d_conv - 1, **factory_kwargs)
+            self.x_proj_b = nn.Linear(self.d_inner, self.dt_rank + self.d_state * 2, bias=False, **factory_kwargs)
+            self.dt_proj_b = nn.Linear(self.dt_rank, self.d_inner, bias=True, **factory_kwargs)
+            self.D_b = nn.Parameter(torch.ones(self.d_inner, device=device))
+            self.D_b._no_weight_decay = True
+
+        self.out_proj = nn.Linear(self.d_inner, self.d_model, bias=bias, **factory_kwargs)
+
+        # this layer's row-index table (int32, device); non-persistent so the state_dict matches the reference
+        perm = None
+        if self.zigzag_paths is not None and layer_idx is not None and not scan_type.startswith("parallelN"):
+            perm = _int32_table(self.zigzag_paths[layer_idx], device)
+        self.register_buffer("_perm", perm, persistent=False)
+        self._rev_cache = {}
+
+    def _s4d_real_log(self, device):
+        A = torch.arange(1, self.d_state + 1, dtype=torch.float32, device=device).repeat(self.d_inner, 1).contiguous()
+        return torch.log(A)
+
+    @staticmethod
+    def _init_dt(dt_proj, dt_init, dt_scale, dt_min, dt_max, dt_init_floor, factory_kwargs):
+        dt_init_std = dt_proj.in_features ** -0.5 * dt_scale
+        if dt_init == "constant":
+            nn.init.constant_(dt_proj.weight, dt_init_std)
+        elif dt_init == "random":
+            nn.init.uniform_(dt_proj.weight, -dt_init_std, dt_init_std)
+        else:
+            raise NotImplementedError
+        dt = torch.exp(torch.rand(dt_proj.out_features, **factory_kwargs) * (math.log(dt_max) - math.log(dt_min))
+                       + math.log(dt_min)).clamp(min=dt_init_floor)
+        inv_dt = dt + torch.log(-torch.expm1(-dt))       # softplus^-1
+        with torch.no_grad():
+            dt_proj.bias.copy_(inv_dt)
+        dt_proj.bias._no_reinit = True
+
+    def forward(self, hidden_states, inference_params=None):
+        return self._mamba_inner_forward(hidden_states, inference_params)
+
+    def _reversed_table(self, L, device):
+        key = (L, str(device))
+        if key not in self._rev_cache:
+            self._rev_cache[key] = torch.arange(L - 1, -1, -1, device=device, dtype=torch.int32)
+        return self._rev_cache[key]
+
+    def _mamba_inner_forward(self, hidden_states, inference_params=None):
+        """hidden_states: (B, L, D) -> (B, L, D)."""
+        if inference_params is not None:
+            raise NotImplementedError("zigma_amd: recurrent decoding is out of scope (ZigMa never passes inference_params)")
+        batch, seqlen, _ = hidden_states.shape
+        xz = F.linear(hidden_states, self.in_proj.weight, self.in_proj.bias)          # (B, L, 2*Di) token-major
+        A = -torch.exp(self.A_log.float())
+        fwd = lambda t, perm: mamba_inner_tok(t, self.conv1d.weight, self.conv1d.bias, self.x_proj.weight,
+                                               self.dt_proj.weight, A, self.D.float(), self.dt_proj.bias.float(),
+                                               perm=perm, delta_softplus=True)
+        st = self.scan_type
+        if st == "v1":
+            y = fwd(xz, None)
+        elif st == "v2":
+            A_b = -torch.exp(self.A_b_log.float())
+            y = fwd(xz, None)
+            y_b = mamba_inner_tok(xz, self.conv1d_b.weight, self.conv1d_b.bias, self.x_proj_b.weight,
+                                  self.dt_proj_b.weight, A_b, self.D_b.float(), self.dt_proj_b.bias.float(),
+                                  perm=self._reversed_table(seqlen, xz.device), delta_softplus=True)
+            y = y + y_b                                   # both already in token order
+        elif st.startswith(("zigzagN", "hilbertN", "randomN")):
+            if self.extras:
+                raise NotImplementedError("extras > 0 is never produced by ZigMa (model_zigma.py:686)")
+            y = fwd(xz, self._perm)
+        elif st.startswith("video_"):
+            T = self.video_frames
+            K = seqlen // T
+            C2 = xz.shape[-1]
+            s_or_t = self.st_order[self.layer_idx]
+            if s_or_t == "s":       # b (t k) c -> (b t) k c : a pure view
+                y = fwd(xz.view(batch * T, K, C2), self._perm).view(batch, seqlen, -1)
+            elif s_or_t == "t":     # b (t k) c -> (b k) t c : one transposing copy in, one out
+                xt = xz.view(batch, T, K, C2).transpose(1, 2).reshape(batch * K, T, C2)
+                yt = fwd(xt, self._perm)
+                y = yt.view(batch, K, T, -1).transpose(1, 2).reshape(batch, seqlen, -1)
+            else:
+                raise NotImplementedError
+        else:
+            raise NotImplementedError
+        return F.linear(y, self.out_proj.weight, self.out_proj.bias)

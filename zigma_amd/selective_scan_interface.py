@@ -1,0 +1,213 @@
+"""Selective-scan op layer on the HIP kernels.
+
+Mirrors the reference's `dis_mamba/mamba_ssm/ops/selective_scan_interface.py` (same names, argument
+order and error behaviour) for the FORWARD path:
+
+    selective_scan_cuda_fwd   <-> selective_scan_cuda.fwd            (selective_scan.cpp:226-336)
+    selective_scan_fn         <-> selective_scan_fn                  (selective_scan_interface.py:77-83)
+    mamba_inner_fn            <-> mamba_inner_fn / MambaInnerFn.forward        (:296-365, :606-614)
+    mamba_inner_fn_no_out_proj<-> MambaInnerFnNoOutProj.forward                (:155-224)
+
+plus `mamba_inner_tok`, the token-major fused form the ZigMa block uses on MI355X: conv, scan and
+the zigzag gather/scatter run on (B, L, C) activations straight out of / into the projection GEMMs,
+so none of the reference's transposes, `index_select`s or `cat`s exist.
+
+Backward (`selective_scan_cuda.bwd`) is the next scope row — these functions do not
+build an autograd graph.
+"""
+import torch
+import torch.nn.functional as F
+
+from . import _lib
+from .causal_conv1d_interface import causal_conv1d_raw
+
+
+def _as_bgnl(M, name):
+    """(B, N, L) -> (B, 1, N, L) like SelectiveScanFn.forward (:30-35)."""
+    if M.dim() == 3:
+        return M.unsqueeze(1)
+    if M.dim() != 4:
+        raise RuntimeError(f"{name} must be (D, N), (B, N, L) or (B, G, N, L)")
+    return M
+
+
+def scan_raw(u, delta, A, B, C, D=None, z=None, delta_bias=None, delta_softplus=False, *, out=None, out_z=None,
+             x=None, z_row_index=None, out_row_index=None, want_out=True):
+    """Launch zigma_selective_scan_fwd.  All tensors are logical (batch, dim, seqlen) VIEWS with arbitrary
+    strides (token-major tensors come in as `.transpose(1, 2)`); B/C are (D, N) f32 or (B, G, N, L) views.
+    Outputs that are None are allocated here with the reference's conventions (out like delta, out_z like z)."""
+    dev = _lib.require_device(u, delta, A, B, C, D, z, delta_bias, out, out_z, x, z_row_index, out_row_index)
+    if u.dim() != 3 or delta.shape != u.shape:
+        raise RuntimeError("u and delta must both be (batch, dim, seqlen)")
+    if A.is_complex():
+        raise RuntimeError("zigma_amd: complex A is out of scope (ZigMa's A is real, mamba_simple.py:298)")
+    if A.dtype != torch.float32:
+        raise RuntimeError("A must be float32")
+    if delta.dtype != u.dtype:
+        raise RuntimeError("delta must have the dtype of u")
+    batch, dim, L = u.shape
+    N = A.shape[1]
+    if A.shape[0] != dim:
+        raise RuntimeError("A must be (dim, dstate)")
+    if N > 256:
+        raise RuntimeError("selective_scan only supports state dimension <= 256")
+    var_b, var_c = B.dim() >= 3, C.dim() >= 3
+    P = _lib.ScanParams()
+    P.batch, P.dim, P.seqlen, P.dstate = batch, dim, L, N
+    P.delta_softplus = int(bool(delta_softplus))
+    P.io_dtype = _lib.dtype_id(u)
+    P.chunk_len, P.flags = 2048, 0
+    P.is_variable_B, P.is_variable_C = int(var_b), int(var_c)
+    groups = 1
+    bc_dt = None
+    for name, M, var in (("B", B, var_b), ("C", C, var_c)):
+        if var:
+            M = _as_bgnl(M, name)
+            if M.shape[0] != batch or M.shape[2] != N or M.shape[3] != L:
+                raise RuntimeError(f"{name} must be (batch, groups, dstate, seqlen)")
+            groups = M.shape[1]
+            if bc_dt is not None and M.dtype != bc_dt:
+                raise RuntimeError("variable B and C must share a dtype")
+            bc_dt = M.dtype
+            sb, sg, sn, sl = M.stride()
+            setattr(P, f"{name}_batch_stride", sb), setattr(P, f"{name}_group_stride", sg)
+            setattr(P, f"{name}_dstate_stride", sn), setattr(P, f"{name}_l_stride", sl)
+        else:
+            if M.shape != (dim, N) or M.dtype != torch.float32:
+                raise RuntimeError(f"constant {name} must be float32 (dim, dstate)")
+            setattr(P, f"{name}_d_stride", M.stride(0)), setattr(P, f"{name}_dstate_stride", M.stride(1))
+        setattr(P, name, _lib.ptr(M))
+        if name == "B":
+            Bk = M
+        else:
+            Ck = M
+    if var_b and var_c and _as_bgnl(B, "B").shape[1] != _as_bgnl(C, "C").shape[1]:
+        raise RuntimeError("B and C must have the same number of groups")
+    if dim % groups != 0:
+        raise RuntimeError("dim must be divisible by the number of B/C groups")
+    P.n_groups = groups
+    P.bc_dtype = _lib.dtype_id(Bk if var_b else (Ck if var_c else u))
+    for name, v in (("D", D), ("delta_bias", delta_bias)):
+        if v is not None:
+            if v.dtype != torch.float32 or v.shape != (dim,):
+                raise RuntimeError(f"{name} must be float32 (dim,)")
+            if v.stride(0) != 1:
+                v = v.contiguous()
+            setattr(P, name, _lib.ptr(v))
+            if name == "D":
+                D = v
+            else:
+                delta_bias = v
+    if z is not None:
+        if z.shape != u.shape or z.dtype != u.dtype:
+            raise RuntimeError("z must match u")
+        if out_z is None:
+            out_z = torch.empty_like(z)
+    if out is None and (want_out or z is None):
+        out = torch.empty_like(delta)
+    for name, t in (("u", u), ("delta", delta), ("z", z), ("out", out), ("out_z", out_z)):
+        if t is None:
+            continue
+        if t.shape != u.shape or t.dtype != u.dtype:
+            raise RuntimeError(f"{name} must match u in shape and dtype")
+        sb, sd, sl = t.stride()
+        setattr(P, name, _lib.ptr(t))
+        setattr(P, f"{name}_batch_stride", sb), setattr(P, f"{name}_d_stride", sd), setattr(P, f"{name}_l_stride", sl)
+    P.A = _lib.ptr(A)
+    P.A_d_stride, P.A_dstate_stride = A.stride()
+    if x is not None:
+        n_chunks = (L + 2047) // 2048
+        if x.shape != (batch, dim, n_chunks, 2 * N) or x.dtype != torch.float32 or not x.is_contiguous():
+            raise RuntimeError("x must be contiguous float32 (batch, dim, n_chunks, 2*dstate)")
+        P.x = _lib.ptr(x)
+    for name, idx in (("z_row_index", z_row_index), ("out_row_index", out_row_index)):
+        if idx is not None:
+            if idx.dtype != torch.int32 or idx.shape != (L,) or not idx.is_contiguous():
+                raise RuntimeError(f"{name} must be a contiguous int32 tensor of length seqlen")
+            setattr(P, name, _lib.ptr(idx))
+    _lib.call("zigma_selective_scan_fwd", P, dev)
+    return out, out_z
+
+
+def selective_scan_cuda_fwd(u, delta, A, B, C, D_, z_, delta_bias_, delta_softplus):
+    """Drop-in for the extension entry `selective_scan_cuda.fwd` -> [out, x] (+ [out_z] if z).
+    Callee allocates: out = empty_like(delta), x (B, D, ceil(L/2048), 2N) f32, out_z = empty_like(z)."""
+    batch, dim, L = u.shape
+    x = torch.empty(batch, dim, (L + 2047) // 2048, 2 * A.shape[1], device=u.device, dtype=torch.float32)
+    out, out_z = scan_raw(u, delta, A, B, C, D_, z_, delta_bias_, delta_softplus, x=x)
+    return [out, x] if z_ is None else [out, x, out_z]
+
+
+def selective_scan_fn(u, delta, A, B, C, D=None, z=None, delta_bias=None, delta_softplus=False,
+                      return_last_state=False):
+    """if return_last_state is True, returns (out, last_state); last_state is (batch, dim, dstate)."""
+    batch, dim, L = u.shape
+    x = None
+    if return_last_state:
+        x = torch.empty(batch, dim, (L + 2047) // 2048, 2 * A.shape[1], device=u.device, dtype=torch.float32)
+    out, out_z = scan_raw(u, delta, A, B, C, D, z, delta_bias, delta_softplus, x=x, want_out=z is None)
+    res = out if z is None else out_z
+    return (res, x[:, :, -1, 1::2]) if return_last_state else res
+
+
+def _inner_common(xz, conv1d_weight, conv1d_bias, x_proj_weight, delta_proj_weight, A, B, C, D, delta_bias,
+                  B_proj_bias, C_proj_bias, delta_softplus):
+    """Reference-layout inner: xz (batch, 2*d_inner, seqlen).  Runs on the token-major kernels internally
+    (one transposing copy in, none out)."""
+    if B is not None or C is not None:
+        raise RuntimeError("zigma_amd: only input-dependent B and C are supported (ZigMa always passes None)")
+    xz_tok = xz.transpose(1, 2).contiguous()                      # (B, L, 2Di)
+    return mamba_inner_tok(xz_tok, conv1d_weight, conv1d_bias, x_proj_weight, delta_proj_weight, A, D, delta_bias,
+                           B_proj_bias=B_proj_bias, C_proj_bias=C_proj_bias, delta_softplus=delta_softplus)
+
+
+def mamba_inner_fn(xz, conv1d_weight, conv1d_bias, x_proj_weight, delta_proj_weight, out_proj_weight, out_proj_bias,
+                   A, B=None, C=None, D=None, delta_bias=None, B_proj_bias=None, C_proj_bias=None,
+                   delta_softplus=True):
+    """xz: (batch, 2*dim, seqlen) -> (batch, seqlen, d_model)."""
+    y = _inner_common(xz, conv1d_weight, conv1d_bias, x_proj_weight, delta_proj_weight, A, B, C, D, delta_bias,
+                      B_proj_bias, C_proj_bias, delta_softplus)
+    return F.linear(y, out_proj_weight, out_proj_bias)
+
+
+def mamba_inner_fn_no_out_proj(xz, conv1d_weight, conv1d_bias, x_proj_weight, delta_proj_weight, A, B=None, C=None,
+                               D=None, delta_bias=None, B_proj_bias=None, C_proj_bias=None, delta_softplus=True):
+    """xz: (batch, 2*dim, seqlen) -> out_z (batch, dim, seqlen)."""
+    y = _inner_common(xz, conv1d_weight, conv1d_bias, x_proj_weight, delta_proj_weight, A, B, C, D, delta_bias,
+                      B_proj_bias, C_proj_bias, delta_softplus)
+    return y.transpose(1, 2)
+
+
+def mamba_inner_tok(xz, conv1d_weight, conv1d_bias, x_proj_weight, delta_proj_weight, A, D, delta_bias, *,
+                    perm=None, B_proj_bias=None, C_proj_bias=None, delta_softplus=True, out=None):
+    """Token-major Mamba inner (no out_proj).
+
+    xz: (batch, seqlen, 2*d_inner), token order, channel contiguous (the in_proj GEMM output as is).
+    perm: optional int32 (seqlen,) device table; the recurrence runs over tokens perm[0], perm[1], ...
+          (zigzag / Hilbert order, reversed order for the backward sweep of `v2`); the result comes back
+          in TOKEN order.  Semantics of mamba_simple.py:362-395: x'[k] = x[perm[k]], out[perm[k]] = out'[k].
+    Returns y (batch, seqlen, d_inner) in token order = out_z of the reference's scan, before out_proj.
+    """
+    if xz.dim() != 3 or xz.stride(2) != 1:
+        raise RuntimeError("xz must be (batch, seqlen, 2*d_inner) with contiguous channels")
+    Bsz, L, C2 = xz.shape
+    Di = C2 // 2
+    R = delta_proj_weight.shape[1]
+    N = A.shape[1]
+    w = conv1d_weight.reshape(Di, -1)
+    x_half, z_half = xz[:, :, :Di], xz[:, :, Di:]
+    # depthwise causal conv + SiLU over the reordered sequence; u is in SCAN order
+    u = torch.empty(Bsz, L, Di, device=xz.device, dtype=xz.dtype)
+    causal_conv1d_raw(x_half.transpose(1, 2), w, conv1d_bias, True, out=u.transpose(1, 2), x_row_index=perm)
+    x_dbl = F.linear(u, x_proj_weight)                               # (B, L, R + 2N)   GEMM
+    delta = F.linear(x_dbl[:, :, :R], delta_proj_weight)             # (B, L, Di)       GEMM
+    Bm, Cm = x_dbl[:, :, R:R + N], x_dbl[:, :, R + N:R + 2 * N]
+    if B_proj_bias is not None:
+        Bm = Bm + B_proj_bias.to(Bm.dtype)
+    if C_proj_bias is not None:
+        Cm = Cm + C_proj_bias.to(Cm.dtype)
+    y = out if out is not None else torch.empty(Bsz, L, Di, device=xz.device, dtype=xz.dtype)
+    scan_raw(u.transpose(1, 2), delta.transpose(1, 2), A, Bm.transpose(1, 2).unsqueeze(1),
+             Cm.transpose(1, 2).unsqueeze(1), D, z_half.transpose(1, 2), delta_bias, delta_softplus,
+             out_z=y.transpose(1, 2), z_row_index=perm, out_row_index=perm, want_out=False)
+    return y
