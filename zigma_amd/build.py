@@ -11,7 +11,7 @@ OBJ = os.path.join(HERE, "build")
 LIB = os.path.join(HERE, "lib", "libzigma_hip.so")
 SOURCES = ["api.hip", "selective_scan.hip", "causal_conv1d.hip", "add_norm.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=fast", "-munsafe-fp-atomics",
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=fast", "-fno-slp-vectorize",
          "-I" + os.path.join(ROOT, "include"), "-I" + CSRC]
 
 

@@ -165,6 +165,7 @@ using namespace zigma;
 
 extern "C" int zigma_add_norm_fwd(const zigma_norm_params_t *pp, void *stream_) {
     if (!pp) return ZIGMA_ERR_NULL;
+    (void)hipGetLastError();  // a stale error of an unrelated earlier call is not ours to report
     const zigma_norm_params_t &p = *pp;
     if (!p.x) return ZIGMA_ERR_NULL;
     if ((p.branch == nullptr) != (p.gate == nullptr)) return ZIGMA_ERR_NULL;

@@ -151,12 +151,13 @@ using namespace zigma;
 
 extern "C" int zigma_causal_conv1d_fwd(const zigma_conv_params_t *pp, void *stream_) {
     if (!pp) return ZIGMA_ERR_NULL;
+    (void)hipGetLastError();  // a stale error of an unrelated earlier call is not ours to report
     const zigma_conv_params_t &p = *pp;
-    if (!p.x || !p.weight || !p.out) return ZIGMA_ERR_NULL;
     if (p.width < 2 || p.width > 4) return ZIGMA_ERR_SHAPE;  // causal_conv1d.cpp:157
     if (p.batch < 0 || p.dim < 0 || p.seqlen < 0) return ZIGMA_ERR_SHAPE;
     if (p.flags != 0) return ZIGMA_ERR_UNSUPPORTED;
-    if (p.batch == 0 || p.dim == 0 || p.seqlen == 0) return ZIGMA_OK;
+    if (p.batch == 0 || p.dim == 0 || p.seqlen == 0) return ZIGMA_OK;  // empty (pointers may be NULL)
+    if (!p.x || !p.weight || !p.out) return ZIGMA_ERR_NULL;
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     ZIGMA_DISPATCH_DTYPE(p.io_dtype, IO, {
         ZIGMA_DISPATCH_DTYPE(p.w_dtype, WT, { return launch_conv<IO, WT>(p, stream); })

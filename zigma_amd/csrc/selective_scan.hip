@@ -4,20 +4,22 @@
 // selective_scan_fwd_kernel.cuh:67-303).  The reference gives one 64-thread block a whole (b, d)
 // row, lays L across the threads and runs `dstate` CUB block scans of (a, b) pairs.  That shape is
 // wrong for this machine: the recurrence is VALU / transcendental bound on CDNA4 (16 exp2 per
-// element against 8 B of HBM traffic), so every cross-lane combine is pure overhead, and B/C would
-// be re-read through L2 by every one of the 1280 channel rows of a sample.
+// element against 8 B of HBM traffic; measured v_exp_f32 ~ 1.8 v_fma_f32 issue slots), so every
+// cross-lane combine of a parallel scan is pure overhead, and B/C would be re-read through L2 by every
+// one of the 1280 channel rows of a sample.
 //
 // Two kernels:
 //
 //  scan_tok_kernel   — the hot path.  Token-major operands (channel contiguous), one LANE per
 //      channel, time runs sequentially inside the lane, so there is NO scan and no cross-lane
-//      traffic: 2 packed FMA-pipe ops + 1 v_exp_f32 per (element, state).  A workgroup owns a
-//      64-channel slab of one sample; its NW waves split the dstate dimension (SPW states each), so
-//      the B_l / C_l values a wave needs are wave-uniform and travel through the SCALAR cache into
-//      SGPRs (zero VGPR / LDS cost).  Per-element work (softplus, D*u, SiLU gate) is done once per
-//      element by a cooperative prologue / epilogue around each LT-step tile and shared through LDS.
-//      The zigzag reordering is two row-index tables applied to whole 128-byte rows (z gather,
-//      out_z scatter): coalesced by construction.
+//      combine: per (element, state) exactly v_mul, v_exp, v_mul, v_fma, v_fmac.  A workgroup owns a
+//      64-channel slab of one sample; its NW waves split the dstate dimension (4 states each).  The
+//      B_l / C_l values of a 4-step group sit in ONE VGPR per operand (lane -> (step, state), the same
+//      16 values in every row of 16 lanes) and reach the FMAs as DPP row_newbcast operands: no SGPR
+//      traffic, no LDS traffic, no extra instruction.  Per-element work (softplus, D*u, SiLU gate) is
+//      done once per element by a cooperative prologue / epilogue around each LT-step tile and shared
+//      through LDS.  The zigzag reordering is two row-index tables applied to whole 128-byte rows
+//      (z gather, out_z scatter): coalesced by construction.
 //
 //  scan_generic_kernel — any strides / constant or grouped B,C / any dstate <= 256: the reference's
 //      full call surface (selective_scan.cpp:233-305).  One row per NS lanes (one lane per state),
@@ -120,44 +122,45 @@ __global__ __launch_bounds__(64) void scan_generic_kernel(const zigma_scan_param
 // token-major kernel
 // =================================================================================================
 
-// SPW wave-uniform B (or C) values of one time step -> SGPRs.  `base` and `off` are wave-uniform, so
-// the loads select to s_load_dword{,x2,x4} and the bf16 widening to SALU shifts.
-template <typename BCT, int SPW>
-__device__ __forceinline__ void load_bc_uniform(const void *base, int64_t off, float (&v)[SPW]) {
-    if constexpr (BCT::id == ZIGMA_F32) {
-        const float *f = reinterpret_cast<const float *>(base) + off;
-#pragma unroll
-        for (int j = 0; j < SPW; ++j) v[j] = f[j];
-    } else {
-        static_assert(BCT::id == ZIGMA_BF16, "fast path carries B/C as f32 or bf16");
-        const uint32_t *w = reinterpret_cast<const uint32_t *>(reinterpret_cast<const uint16_t *>(base) + off);
-#pragma unroll
-        for (int j = 0; j < SPW / 2; ++j) {
-            const uint32_t x = w[j];
-            v[2 * j] = __uint_as_float(x << 16);
-            v[2 * j + 1] = __uint_as_float(x & 0xffff0000u);
-        }
-    }
+// lane M (0..15) of every 16-lane row, broadcast to the whole row: DPP row_newbcast (gfx90a+).  With full
+// row/bank masks the compiler folds it into the consuming v_mul_f32 / v_fmac_f32 as a DPP source operand.
+template <int M>
+__device__ __forceinline__ float row_bcast(float v) {
+    return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x150 + M, 0xf, 0xf, true));
 }
+// y += row_bcast<M>(c) * h as ONE v_fmac_f32_dpp (hipcc folds DPP into v_mul but not into the tied-operand
+// fmac).  A VALU write of `c` needs 2 wait states before a DPP read of it and nothing inside an asm statement
+// is padded by the compiler: pass every freshly produced `c` through dpp_settle() once.
+template <int M>
+__device__ __forceinline__ void fmac_bcast(float &y, float c, float h) {
+    asm("v_fmac_f32_dpp %0, %1, %2 row_newbcast:%c3 row_mask:0xf bank_mask:0xf bound_ctrl:1"
+        : "+v"(y) : "v"(c), "v"(h), "i"(M));
+}
+__device__ __forceinline__ void dpp_settle(float &c) { asm volatile("s_nop 1" : "+v"(c)); }
 
-template <typename IO, typename BCT, int SPW, int NW, int LT, bool HAS_Z, bool HAS_X>
-__global__ __launch_bounds__(64 * NW) void scan_tok_kernel(const zigma_scan_params_t p) {
-    static_assert(LT % NW == 0 && LT % 2 == 0, "tile rows split evenly over the waves");
+constexpr int kSPW = 4;  // states per wave (one DPP row = 4 steps x 4 states)
+
+template <typename IO, typename BCT, int NW, int LT, bool HAS_Z>
+__global__ __launch_bounds__(64 * NW, (5 * 4) / NW >= 5 ? 5 : 4) void scan_tok_kernel(const zigma_scan_params_t p) {
+    const bool HAS_X = p.x != nullptr;
+    static_assert(LT % NW == 0 && LT % 4 == 0, "tile rows split evenly over the waves, 4-step B/C groups");
     constexpr int RPT = LT / NW;  // tile rows handled by one wave in the cooperative phases
+    constexpr int NG = LT / 4;    // 4-step groups per tile
     // [buf][step pair][channel][sp0, du0, sp1, du1]  -> one ds_read_b128 feeds two steps
     __shared__ __attribute__((aligned(16))) float s_spdu[2][LT / 2][64][4];
-    __shared__ __attribute__((aligned(16))) float s_y[NW][LT][64];  // per-wave partial y
+    // per-wave partial y: [wave][step pair][channel][2] -> one ds_write_b64 per two steps
+    __shared__ __attribute__((aligned(16))) float s_y[NW][LT / 2][64][2];
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int b = blockIdx.y;
     const int c = blockIdx.x * 64 + lane;  // channel of this lane
     const int L = p.seqlen;
-    const int n0 = wave * SPW;
+    const int n0 = wave * kSPW;
 
-    float a2[SPW], h[SPW];
+    float a2[kSPW], h[kSPW];
 #pragma unroll
-    for (int j = 0; j < SPW; ++j) {
+    for (int j = 0; j < kSPW; ++j) {
         a2[j] = reinterpret_cast<const float *>(p.A)[c * p.A_d_stride + (n0 + j) * p.A_dstate_stride] * kLog2e;
         h[j] = 0.f;
     }
@@ -165,33 +168,51 @@ __global__ __launch_bounds__(64 * NW) void scan_tok_kernel(const zigma_scan_para
     const float bias = p.delta_bias ? reinterpret_cast<const float *>(p.delta_bias)[c] : 0.f;
     const bool sp_on = p.delta_softplus != 0;
 
-    const int64_t u_off = b * p.u_batch_stride + c;
-    const int64_t dl_off = b * p.delta_batch_stride + c;
-    const int64_t z_off = b * p.z_batch_stride + c;
-    const int64_t o_off = b * p.out_batch_stride + c;
-    const int64_t oz_off = b * p.out_z_batch_stride + c;
-    const int64_t B_off = b * p.B_batch_stride + n0;
-    const int64_t C_off = b * p.C_batch_stride + n0;
+    // per-sample base pointers (64-bit, once); inside a sample every offset fits 32 bits (dispatcher checks)
+    using io_t = typename IO::raw;
+    using bc_t = typename BCT::raw;
+    const io_t *up = reinterpret_cast<const io_t *>(p.u) + b * p.u_batch_stride + c;
+    const io_t *dp = reinterpret_cast<const io_t *>(p.delta) + b * p.delta_batch_stride + c;
+    const io_t *zp = reinterpret_cast<const io_t *>(p.z) + b * p.z_batch_stride + c;
+    io_t *op = reinterpret_cast<io_t *>(p.out) + b * p.out_batch_stride + c;
+    io_t *ozp = reinterpret_cast<io_t *>(p.out_z) + b * p.out_z_batch_stride + c;
+    const int u_ls = static_cast<int>(p.u_l_stride), d_ls = static_cast<int>(p.delta_l_stride);
+    const int z_ls = static_cast<int>(p.z_l_stride), o_ls = static_cast<int>(p.out_l_stride);
+    const int oz_ls = static_cast<int>(p.out_z_l_stride);
+    const int B_ls = static_cast<int>(p.B_l_stride), C_ls = static_cast<int>(p.C_l_stride);
+    // B/C group register: lane -> (step s = (lane & 15) >> 2, state j = lane & 3)
+    const int bc_s = (lane & 15) >> 2;
+    const bc_t *Bp = reinterpret_cast<const bc_t *>(p.B) + b * p.B_batch_stride + (n0 + (lane & 3)) * p.B_dstate_stride;
+    const bc_t *Cp = reinterpret_cast<const bc_t *>(p.C) + b * p.C_batch_stride + (n0 + (lane & 3)) * p.C_dstate_stride;
     const int chunk_len = p.chunk_len > 0 ? p.chunk_len : 2048;
     const int n_chunks = (L + chunk_len - 1) / chunk_len;
     float cum = 0.f;
 
-    struct Rows { float u[RPT], d[RPT], z[RPT]; };  // this wave's rows of one tile, in registers
+    struct Rows { float u[RPT], d[RPT], z[RPT]; };   // this wave's rows of one tile
+    struct BC { typename BCT::raw b[NG], c[NG]; };   // this wave's B/C of one tile
     Rows ra, rb;
+    BC ba, bb;
 
-    auto issue_loads = [&](int t, Rows &rw) {
+    auto issue_loads = [&](int t, Rows &rw, BC &bc) {
 #pragma unroll
         for (int i = 0; i < RPT; ++i) {
             const int k = t * LT + wave * RPT + i;
             const bool ok = k < L;
             const int kk = ok ? k : L - 1;
-            rw.u[i] = ld<IO>(p.u, u_off + kk * p.u_l_stride);
-            rw.d[i] = ld<IO>(p.delta, dl_off + kk * p.delta_l_stride);
+            rw.u[i] = to_float<IO>(up[kk * u_ls]);
+            rw.d[i] = to_float<IO>(dp[kk * d_ls]);
             if constexpr (HAS_Z) {
-                const int64_t zrow = p.z_row_index ? p.z_row_index[kk] : kk;
-                rw.z[i] = ld<IO>(p.z, z_off + zrow * p.z_l_stride);
+                const int zrow = p.z_row_index ? p.z_row_index[kk] : kk;
+                rw.z[i] = to_float<IO>(zp[zrow * z_ls]);
             }
             if (!ok) { rw.u[i] = 0.f; rw.d[i] = 0.f; }
+        }
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+            int k = t * LT + g * 4 + bc_s;
+            if (k >= L) k = L - 1;  // padded steps carry du = 0
+            bc.b[g] = Bp[k * B_ls];
+            bc.c[g] = Cp[k * C_ls];
         }
     };
     // cooperative prologue of tile t: softplus, delta*u -> LDS
@@ -202,7 +223,7 @@ __global__ __launch_bounds__(64 * NW) void scan_tok_kernel(const zigma_scan_para
             const int k = t * LT + r;
             float dv = rw.d[i] + bias;
             if (sp_on) dv = softplus20(dv);
-            if (k >= L) dv = 0.f;  // identity step: a = 1, b = 0
+            if (k >= L) dv = 0.f;  // identity step: a = 1, b = 0 (h and cum stay put)
             const float du = dv * rw.u[i];
             v2f w = {dv, du};
             *reinterpret_cast<v2f *>(&s_spdu[t & 1][r >> 1][lane][(r & 1) * 2]) = w;
@@ -211,46 +232,55 @@ __global__ __launch_bounds__(64 * NW) void scan_tok_kernel(const zigma_scan_para
 
     const int n_tiles = (L + LT - 1) / LT;
 
-    // one tile: prefetch rows of t+1 -> recurrence over t -> stage t+1 -> barrier -> epilogue of t
-    auto tile = [&](int t, Rows &cur, Rows &nxt) {
-        const int s = t & 1;
-        if (t + 1 < n_tiles) issue_loads(t + 1, nxt);
+    // one step of the recurrence for this lane's 4 states; S = step inside the 4-step group
+#define ZIGMA_STEP(S, dv, du, Bf, Cf, yv)                                        \
+    {                                                                            \
+        const float e0 = fast_exp2((dv) * a2[0]), e1 = fast_exp2((dv) * a2[1]);  \
+        const float e2 = fast_exp2((dv) * a2[2]), e3 = fast_exp2((dv) * a2[3]);  \
+        h[0] = __builtin_fmaf(e0, h[0], row_bcast<(S) * 4 + 0>(Bf) * (du));      \
+        h[1] = __builtin_fmaf(e1, h[1], row_bcast<(S) * 4 + 1>(Bf) * (du));      \
+        h[2] = __builtin_fmaf(e2, h[2], row_bcast<(S) * 4 + 2>(Bf) * (du));      \
+        h[3] = __builtin_fmaf(e3, h[3], row_bcast<(S) * 4 + 3>(Bf) * (du));      \
+        yv = 0.f;                                                                \
+        fmac_bcast<(S) * 4 + 0>(yv, Cf, h[0]);                                   \
+        fmac_bcast<(S) * 4 + 1>(yv, Cf, h[1]);                                   \
+        fmac_bcast<(S) * 4 + 2>(yv, Cf, h[2]);                                   \
+        fmac_bcast<(S) * 4 + 3>(yv, Cf, h[3]);                                   \
+    }
 
-        // ---- recurrence over the tile: this wave's SPW states of 64 channels ------------------
-        const int64_t kb = static_cast<int64_t>(t) * LT;
+    // one tile: prefetch rows of t+1 -> recurrence over t -> stage t+1 -> barrier -> epilogue of t
+    auto tile = [&](int t, Rows &cur, Rows &nxt, const BC &bcur, BC &bnxt) {
+        const int s = t & 1;
+        if (t + 1 < n_tiles) issue_loads(t + 1, nxt, bnxt);
+
 #pragma unroll
-        for (int l2 = 0; l2 < LT / 2; ++l2) {
-            const v4f q = *reinterpret_cast<const v4f *>(&s_spdu[s][l2][lane][0]);
+        for (int g = 0; g < NG; ++g) {
+            const float Bf = to_float<BCT>(bcur.b[g]);
+            float Cf = to_float<BCT>(bcur.c[g]);
+            dpp_settle(Cf);
+            const v4f q0 = *reinterpret_cast<const v4f *>(&s_spdu[s][g * 2][lane][0]);
+            const v4f q1 = *reinterpret_cast<const v4f *>(&s_spdu[s][g * 2 + 1][lane][0]);
+            float y0, y1, y2, y3;
+            ZIGMA_STEP(0, q0.x, q0.y, Bf, Cf, y0)
+            ZIGMA_STEP(1, q0.z, q0.w, Bf, Cf, y1)
+            *reinterpret_cast<v2f *>(&s_y[wave][g * 2][lane][0]) = v2f{y0, y1};
+            ZIGMA_STEP(2, q1.x, q1.y, Bf, Cf, y2)
+            ZIGMA_STEP(3, q1.z, q1.w, Bf, Cf, y3)
+            *reinterpret_cast<v2f *>(&s_y[wave][g * 2 + 1][lane][0]) = v2f{y2, y3};
+            if (HAS_X) cum += (q0.x + q0.z) + (q1.x + q1.z);
+        }
+        if (HAS_X) {
+            // carries at chunk ends.  chunk_len is a multiple of LT (dispatcher), so a chunk end is a tile end;
+            // the sequence end may fall inside the last tile, whose padded steps are identities.
+            const int64_t k_next = (static_cast<int64_t>(t) + 1) * LT;
+            if (t == n_tiles - 1 || k_next % chunk_len == 0) {
+                const int64_t k_eff = (k_next <= L ? k_next : L) - 1;
+                float *xr = reinterpret_cast<float *>(p.x) +
+                            ((static_cast<int64_t>(b) * p.dim + c) * n_chunks + k_eff / chunk_len) * 2 * p.dstate;
 #pragma unroll
-            for (int e = 0; e < 2; ++e) {
-                const int l = l2 * 2 + e;
-                const float dv = e ? q.z : q.x;
-                const float du = e ? q.w : q.y;
-                int64_t k = kb + l;
-                if (k >= L) k = L - 1;  // B/C of padded steps are multiplied by du = 0
-                float Bv[SPW], Cv[SPW];
-                load_bc_uniform<BCT, SPW>(p.B, B_off + k * p.B_l_stride, Bv);
-                load_bc_uniform<BCT, SPW>(p.C, C_off + k * p.C_l_stride, Cv);
-                float y = 0.f;
-#pragma unroll
-                for (int j = 0; j < SPW; ++j) {
-                    const float a = fast_exp2(dv * a2[j]);
-                    h[j] = a * h[j] + du * Bv[j];
-                    y += h[j] * Cv[j];
-                }
-                s_y[wave][l][lane] = y;
-                if constexpr (HAS_X) {
-                    cum += dv;
-                    const int64_t kk = kb + l;
-                    if (kk < L && ((kk + 1) % chunk_len == 0 || kk == L - 1)) {
-                        float *xr = reinterpret_cast<float *>(p.x) +
-                                    ((static_cast<int64_t>(b) * p.dim + c) * n_chunks + kk / chunk_len) * 2 * p.dstate;
-#pragma unroll
-                        for (int j = 0; j < SPW; ++j) {
-                            xr[2 * (n0 + j)] = fast_exp2(cum * a2[j]);
-                            xr[2 * (n0 + j) + 1] = h[j];
-                        }
-                    }
+                for (int j = 0; j < kSPW; ++j) {
+                    xr[2 * (n0 + j)] = fast_exp2(cum * a2[j]);
+                    xr[2 * (n0 + j) + 1] = h[j];
                 }
             }
         }
@@ -265,37 +295,33 @@ __global__ __launch_bounds__(64 * NW) void scan_tok_kernel(const zigma_scan_para
             if (k < L) {
                 float y = Dv * cur.u[i];
 #pragma unroll
-                for (int w = 0; w < NW; ++w) y += s_y[w][r][lane];
-                const int64_t orow = p.out_row_index ? p.out_row_index[k] : k;
-                if (p.out) st<IO>(p.out, o_off + orow * p.out_l_stride, y);
-                if constexpr (HAS_Z) st<IO>(p.out_z, oz_off + orow * p.out_z_l_stride, y * silu(cur.z[i]));
+                for (int w = 0; w < NW; ++w) y += s_y[w][r >> 1][lane][r & 1];
+                const int orow = p.out_row_index ? p.out_row_index[k] : k;
+                if (p.out) op[orow * o_ls] = from_float<IO>(y);
+                if constexpr (HAS_Z) ozp[orow * oz_ls] = from_float<IO>(y * silu(cur.z[i]));
             }
         }
         __syncthreads();
     };
+#undef ZIGMA_STEP
 
-    issue_loads(0, ra);
+    issue_loads(0, ra, ba);
     stage(0, ra);
     __syncthreads();
     for (int t = 0; t < n_tiles; t += 2) {
-        tile(t, ra, rb);
-        if (t + 1 < n_tiles) tile(t + 1, rb, ra);
+        tile(t, ra, rb, ba, bb);
+        if (t + 1 < n_tiles) tile(t + 1, rb, ra, bb, ba);
     }
 }
 
 // =================================================================================================
 // host dispatch
 // =================================================================================================
-static bool aligned(const void *ptr, size_t a) { return (reinterpret_cast<uintptr_t>(ptr) % a) == 0; }
-
-template <typename IO, typename BCT, int SPW, int NW, int LT>
+template <typename IO, typename BCT, int NW, int LT>
 static int launch_tok(const zigma_scan_params_t &p, hipStream_t stream, const char *name) {
     dim3 grid(p.dim / 64, p.batch), block(64 * NW);
-    const bool has_z = p.z != nullptr, has_x = p.x != nullptr;
-    if (has_z && has_x) hipLaunchKernelGGL((scan_tok_kernel<IO, BCT, SPW, NW, LT, true, true>), grid, block, 0, stream, p);
-    else if (has_z) hipLaunchKernelGGL((scan_tok_kernel<IO, BCT, SPW, NW, LT, true, false>), grid, block, 0, stream, p);
-    else if (has_x) hipLaunchKernelGGL((scan_tok_kernel<IO, BCT, SPW, NW, LT, false, true>), grid, block, 0, stream, p);
-    else hipLaunchKernelGGL((scan_tok_kernel<IO, BCT, SPW, NW, LT, false, false>), grid, block, 0, stream, p);
+    if (p.z != nullptr) hipLaunchKernelGGL((scan_tok_kernel<IO, BCT, NW, LT, true>), grid, block, 0, stream, p);
+    else hipLaunchKernelGGL((scan_tok_kernel<IO, BCT, NW, LT, false>), grid, block, 0, stream, p);
     set_last_kernel(name);
     return check_launch();
 }
@@ -324,23 +350,23 @@ static int launch_generic(const zigma_scan_params_t &p, hipStream_t stream) {
     return check_launch();
 }
 
-// token-major fast path applies when channels are contiguous everywhere and B/C rows hold the
-// dstate values of one token contiguously (x_dbl rows of the fused block).
+// token-major fast path: channels contiguous in u / delta / z / out, input-dependent B and C (any
+// strides), dstate 16 (4 waves x 4 states) or 8 (2 waves), dim a multiple of the 64-channel slab.
 static bool tok_eligible(const zigma_scan_params_t &p) {
     if (!p.is_variable_B || !p.is_variable_C || p.n_groups != 1) return false;
-    if (p.dim % 64 != 0 || p.dstate != 16) return false;
+    if (p.dim % 64 != 0 || (p.dstate != 16 && p.dstate != 8)) return false;
     if (p.u_d_stride != 1 || p.delta_d_stride != 1) return false;
     if (p.z && (p.z_d_stride != 1 || p.out_z_d_stride != 1)) return false;
     if (p.out && p.out_d_stride != 1) return false;
-    if (!p.z && !p.out) return false;
-    if (p.B_dstate_stride != 1 || p.C_dstate_stride != 1) return false;
-    if (p.A_dstate_stride != 1) return false;
-    if (p.bc_dtype == ZIGMA_F16) return false;
-    const size_t es = p.bc_dtype == ZIGMA_F32 ? 4 : 2;
-    // every SPW-group of B/C must start on a dword (scalar loads): 4 states * es bytes per group
-    if (!aligned(p.B, 4) || !aligned(p.C, 4)) return false;
-    if ((p.B_l_stride * es) % 4 || (p.C_l_stride * es) % 4 || (p.B_batch_stride * es) % 4 || (p.C_batch_stride * es) % 4)
-        return false;
+    const int chunk_len = p.chunk_len > 0 ? p.chunk_len : 2048;
+    if (p.x && chunk_len % 16 != 0) return false;  // carries are stored at tile ends
+    if (p.bc_dtype != p.io_dtype) return false;    // instantiation set: B/C in the activation dtype
+    // in-sample offsets are 32-bit in the kernel
+    const int64_t lim = (int64_t(1) << 31) - 1, Lm = p.seqlen;
+    const int64_t ls[] = {p.u_l_stride, p.delta_l_stride, p.z ? p.z_l_stride : 0, p.out ? p.out_l_stride : 0,
+                          p.z ? p.out_z_l_stride : 0, p.B_l_stride, p.C_l_stride};
+    for (int64_t s : ls)
+        if (s < 0 || s * Lm > lim) return false;
     return true;
 }
 
@@ -350,33 +376,22 @@ using namespace zigma;
 
 extern "C" int zigma_selective_scan_fwd(const zigma_scan_params_t *pp, void *stream_) {
     if (!pp) return ZIGMA_ERR_NULL;
+    (void)hipGetLastError();  // a stale error of an unrelated earlier call is not ours to report
     const zigma_scan_params_t &p = *pp;
     hipStream_t stream = static_cast<hipStream_t>(stream_);
-    if (!p.u || !p.delta || !p.A || !p.B || !p.C) return ZIGMA_ERR_NULL;
-    if (p.z && !p.out_z) return ZIGMA_ERR_NULL;
-    if (!p.z && !p.out) return ZIGMA_ERR_NULL;
     if (p.batch < 0 || p.dim < 0 || p.seqlen < 0 || p.dstate < 1 || p.dstate > 256) return ZIGMA_ERR_SHAPE;  // MAX_DSTATE
     if (p.n_groups < 1 || p.dim % p.n_groups != 0) return ZIGMA_ERR_SHAPE;
     if (p.flags != 0) return ZIGMA_ERR_UNSUPPORTED;
-    if (p.batch == 0 || p.dim == 0 || p.seqlen == 0) return ZIGMA_OK;  // empty: nothing to launch
+    if (p.batch == 0 || p.dim == 0 || p.seqlen == 0) return ZIGMA_OK;  // empty (pointers may be NULL): nothing to launch
+    if (!p.u || !p.delta || !p.A || !p.B || !p.C) return ZIGMA_ERR_NULL;
+    if (p.z && !p.out_z) return ZIGMA_ERR_NULL;
+    if (!p.z && !p.out) return ZIGMA_ERR_NULL;
 
     if (tok_eligible(p)) {
-        // states-per-wave split: enough workgroups to fill 256 CUs x 4 SIMDs, else keep whole rows per wave
-        const int64_t slabs = static_cast<int64_t>(p.dim / 64) * p.batch;
-        const int forced = 0;
-        (void)forced;
-        if (p.bc_dtype == ZIGMA_BF16) {
-            ZIGMA_DISPATCH_DTYPE(p.io_dtype, IO, {
-                if (slabs >= 4096) return launch_tok<IO, BF16, 16, 1, 16>(p, stream, "scan_tok_s16w1");
-                if (slabs >= 2048) return launch_tok<IO, BF16, 8, 2, 16>(p, stream, "scan_tok_s8w2");
-                return launch_tok<IO, BF16, 4, 4, 16>(p, stream, "scan_tok_s4w4");
-            })
-        } else {
-            ZIGMA_DISPATCH_DTYPE(p.io_dtype, IO, {
-                if (slabs >= 2048) return launch_tok<IO, F32, 8, 2, 8>(p, stream, "scan_tok_s8w2");
-                return launch_tok<IO, F32, 4, 4, 8>(p, stream, "scan_tok_s4w4");
-            })
-        }
+        ZIGMA_DISPATCH_DTYPE(p.io_dtype, IO, {
+            if (p.dstate == 16) return launch_tok<IO, IO, 4, 16>(p, stream, "scan_tok_n16");
+            return launch_tok<IO, IO, 2, 16>(p, stream, "scan_tok_n8");
+        })
     }
     ZIGMA_DISPATCH_DTYPE(p.io_dtype, IO, {
         ZIGMA_DISPATCH_DTYPE(p.bc_dtype, BCT, { return launch_generic<IO, BCT>(p, stream); })

@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdio.h>
 
 #include "zigma_hip.h"
 
@@ -33,11 +34,11 @@ template <> __device__ __forceinline__ float to_float<F16>(uint16_t v) {
 template <typename T> __device__ __forceinline__ typename T::raw from_float(float f);
 template <> __device__ __forceinline__ float from_float<F32>(float f) { return f; }
 template <> __device__ __forceinline__ uint16_t from_float<BF16>(float f) {
-    // round-to-nearest-even, NaN kept quiet (same as at::BFloat16)
-    uint32_t u = __float_as_uint(f);
-    if ((u & 0x7fffffffu) > 0x7f800000u) return static_cast<uint16_t>((u >> 16) | 0x40u);
-    u += 0x7fffu + ((u >> 16) & 1u);
-    return static_cast<uint16_t>(u >> 16);
+    // round-to-nearest-even (same as at::BFloat16); one v_cvt_pk_bf16_f32 on gfx950
+    const __bf16 h = static_cast<__bf16>(f);
+    uint16_t v;
+    __builtin_memcpy(&v, &h, 2);
+    return v;
 }
 template <> __device__ __forceinline__ uint16_t from_float<F16>(float f) {
     _Float16 h = static_cast<_Float16>(f);
@@ -66,9 +67,9 @@ __device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcp
 // very negative x, where 1+t would round t away), hardware log2 otherwise.
 __device__ __forceinline__ float softplus20(float x) {
     const float t = fast_exp2(fminf(x, 20.f) * kLog2e);
-    const float series = t * (1.f + t * (-0.5f + t * (0.33333334f + t * (-0.25f + t * 0.2f))));
-    const float big = fast_log2(1.f + t) * kLn2;
-    const float sp = t < 0.0625f ? series : big;
+    const float series = t * (1.f + t * (-0.5f + t * 0.33333334f));   // |err| < t^4/4 <= 6e-8 t  for t < 2^-6
+    const float big = fast_log2(1.f + t) * kLn2;                       // abs err ~1e-7 on a result >= 0.0155
+    const float sp = t < 0.015625f ? series : big;
     return x > 20.f ? x : sp;
 }
 
@@ -76,7 +77,12 @@ __device__ __forceinline__ float softplus20(float x) {
 __device__ __forceinline__ float silu(float z) { return z * fast_rcp(1.f + fast_exp2(-z * kLog2e)); }
 
 // ---- host side -----------------------------------------------------------------------------------
-inline int check_launch() { return hipGetLastError() == hipSuccess ? ZIGMA_OK : ZIGMA_ERR_LAUNCH; }
+inline int check_launch() {
+    const hipError_t e = hipGetLastError();
+    if (e == hipSuccess) return ZIGMA_OK;
+    fprintf(stderr, "libzigma_hip: kernel launch failed: %s (%s)\n", hipGetErrorName(e), hipGetErrorString(e));
+    return ZIGMA_ERR_LAUNCH;
+}
 void set_last_kernel(const char *name);
 
 #define ZIGMA_DISPATCH_DTYPE(DT, T, ...)                                   \

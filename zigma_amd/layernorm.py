@@ -10,7 +10,7 @@ from . import _lib
 
 
 def _norm_call(x2, weight, bias, residual2, eps, is_rms, residual_dtype, *, rows_per_batch=None, branch=None,
-               gate=None, x_out=None, shift=None, scale=None, want_y=True):
+               gate=None, x_out=None, shift=None, scale=None, want_y=True, want_res=None):
     dev = _lib.require_device(x2, weight, bias, residual2, branch, gate, shift, scale)
     rows, cols = x2.shape
     P = _lib.NormParams()
@@ -27,7 +27,9 @@ def _norm_call(x2, weight, bias, residual2, eps, is_rms, residual_dtype, *, rows
         P.residual, P.res_row_stride = _lib.ptr(residual2), residual2.stride(0)
         residual_dtype = residual2.dtype
     P.res_dtype = _lib._DT.get(residual_dtype if residual_dtype is not None else x2.dtype)
-    if residual2 is not None or (residual_dtype is not None and residual_dtype != x2.dtype):
+    if want_res is None:
+        want_res = residual2 is not None or (residual_dtype is not None and residual_dtype != x2.dtype)
+    if want_res:
         res_out = torch.empty(rows, cols, device=x2.device, dtype=residual_dtype or x2.dtype)
         P.residual_out, P.res_out_row_stride = _lib.ptr(res_out), res_out.stride(0)
     P.w_dtype = _lib.dtype_id(weight) if weight is not None else P.x_dtype
@@ -104,7 +106,7 @@ class RMSNorm(torch.nn.Module):
 
 
 def block_norm(x, weight, bias, residual, eps, is_rms, *, residual_in_fp32=True, branch=None, gate=None,
-               shift=None, scale=None, want_x=False, want_y=True):
+               shift=None, scale=None, want_x=False, want_y=True, want_res_out=True):
     """One launch for the glue around a ZigMa sub-layer (model_zigma.py:415-458), on (B, L, E) tensors:
 
         xe  = x + gate[:, None] * branch          (if branch is given; the previous sub-layer's gated output)
@@ -116,8 +118,14 @@ def block_norm(x, weight, bias, residual, eps, is_rms, *, residual_in_fp32=True,
     x2 = _flat(x)
     xe = torch.empty_like(x2) if (branch is not None and want_x) else None
     res_dtype = residual.dtype if residual is not None else (torch.float32 if residual_in_fp32 else None)
+    # the residual stream comes back whenever the kernel changes it (add, cast or gated branch); otherwise the
+    # reference hands x itself back (layernorm.py:177) and so do we
+    want_res = want_res_out and (residual is not None or branch is not None or
+                                 (res_dtype is not None and res_dtype != x2.dtype))
     y, res_out, ym = _norm_call(x2, weight, bias, _flat(residual) if residual is not None else None, eps, is_rms,
                                 res_dtype, rows_per_batch=L, branch=_flat(branch) if branch is not None else None,
-                                gate=gate, x_out=xe, shift=shift, scale=scale, want_y=want_y)
+                                gate=gate, x_out=xe, shift=shift, scale=scale, want_y=want_y, want_res=want_res)
+    if want_res_out and res_out is None:
+        res_out = x2
     rs = lambda t: None if t is None else t.reshape(Bsz, L, E)
     return rs(xe), rs(res_out), rs(y), rs(ym)

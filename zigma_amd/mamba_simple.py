@@ -106,6 +106,16 @@ class Mamba(nn.Module):
         if self.zigzag_paths is not None and layer_idx is not None and not scan_type.startswith("parallelN"):
             perm = _int32_table(self.zigzag_paths[layer_idx], device)
         self.register_buffer("_perm", perm, persistent=False)
+        # write-back table: out = out'[:, perm_rev]  <=>  out[inverse(perm_rev)[k]] = out'[k].  Equal to _perm when
+        # perm_rev really is perm's inverse (zigzag / hilbert); NOT for the reference's temporal tables, which
+        # pair [0..T-1] with [T-1..0] (model_zigma.py:765-772) — kept bit-for-bit.
+        out_rows = None
+        if perm is not None and self.zigzag_paths_reverse is not None:
+            rev = torch.as_tensor(self.zigzag_paths_reverse[layer_idx]).to("cpu", torch.int64)
+            inv = torch.empty_like(rev)
+            inv[rev] = torch.arange(rev.numel(), dtype=torch.int64)
+            out_rows = _int32_table(inv, device)
+        self.register_buffer("_out_rows", out_rows, persistent=False)
         self._rev_cache = {}
 
     def _s4d_real_log(self, device):
@@ -146,7 +156,8 @@ class Mamba(nn.Module):
         A = -torch.exp(self.A_log.float())
         fwd = lambda t, perm: mamba_inner_tok(t, self.conv1d.weight, self.conv1d.bias, self.x_proj.weight,
                                                self.dt_proj.weight, A, self.D.float(), self.dt_proj.bias.float(),
-                                               perm=perm, delta_softplus=True)
+                                               perm=perm, out_rows=self._out_rows if perm is self._perm else None,
+                                               delta_softplus=True)
         st = self.scan_type
         if st == "v1":
             y = fwd(xz, None)

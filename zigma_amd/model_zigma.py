@@ -221,7 +221,7 @@ class Block(nn.Module):
             return Pending(n, mix, mod[:, 2 * E:3 * E]), residual
         h, _, _, xa = block_norm(n, None, None, None, self.norm_msa.eps, False, residual_in_fp32=False, branch=mix,
                                  gate=mod[:, 2 * E:3 * E], shift=mod[:, 3 * E:4 * E], scale=mod[:, 4 * E:5 * E],
-                                 want_x=True, want_y=False)
+                                 want_x=True, want_y=False, want_res_out=False)
         att = self.msa(xa, text=text, mask=None)
         return Pending(h, att, mod[:, 5 * E:6 * E]), residual
 

@@ -179,13 +179,17 @@ def mamba_inner_fn_no_out_proj(xz, conv1d_weight, conv1d_bias, x_proj_weight, de
 
 
 def mamba_inner_tok(xz, conv1d_weight, conv1d_bias, x_proj_weight, delta_proj_weight, A, D, delta_bias, *,
-                    perm=None, B_proj_bias=None, C_proj_bias=None, delta_softplus=True, out=None):
+                    perm=None, out_rows=None, B_proj_bias=None, C_proj_bias=None, delta_softplus=True, out=None):
     """Token-major Mamba inner (no out_proj).
 
     xz: (batch, seqlen, 2*d_inner), token order, channel contiguous (the in_proj GEMM output as is).
     perm: optional int32 (seqlen,) device table; the recurrence runs over tokens perm[0], perm[1], ...
           (zigzag / Hilbert order, reversed order for the backward sweep of `v2`); the result comes back
           in TOKEN order.  Semantics of mamba_simple.py:362-395: x'[k] = x[perm[k]], out[perm[k]] = out'[k].
+    out_rows: optional int32 (seqlen,) table for the write-back when it is NOT the inverse of the gather:
+          out[out_rows[k]] = out'[k] (defaults to perm).  The reference pairs its temporal table [0..T-1] with
+          the "reverse" table [T-1..0] (model_zigma.py:765-772), i.e. out = out'[:, perm_rev] with perm_rev not
+          the inverse of perm; the caller passes out_rows = inverse(perm_rev) to reproduce exactly that.
     Returns y (batch, seqlen, d_inner) in token order = out_z of the reference's scan, before out_proj.
     """
     if xz.dim() != 3 or xz.stride(2) != 1:
@@ -209,5 +213,6 @@ def mamba_inner_tok(xz, conv1d_weight, conv1d_bias, x_proj_weight, delta_proj_we
     y = out if out is not None else torch.empty(Bsz, L, Di, device=xz.device, dtype=xz.dtype)
     scan_raw(u.transpose(1, 2), delta.transpose(1, 2), A, Bm.transpose(1, 2).unsqueeze(1),
              Cm.transpose(1, 2).unsqueeze(1), D, z_half.transpose(1, 2), delta_bias, delta_softplus,
-             out_z=y.transpose(1, 2), z_row_index=perm, out_row_index=perm, want_out=False)
+             out_z=y.transpose(1, 2), z_row_index=perm, out_row_index=perm if out_rows is None else out_rows,
+             want_out=False)
     return y
