@@ -9,7 +9,8 @@ ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(HERE, "build")
 LIB = os.path.join(HERE, "lib", "libzigma_hip.so")
-SOURCES = ["api.hip", "selective_scan.hip", "causal_conv1d.hip", "add_norm.hip"]
+SOURCES = ["api.hip", "selective_scan.hip", "scan_tok_bf16.hip", "scan_tok_f16.hip", "scan_tok_f32.hip",
+           "causal_conv1d.hip", "add_norm.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=fast", "-fno-slp-vectorize",
          "-I" + os.path.join(ROOT, "include"), "-I" + CSRC]
@@ -27,7 +28,7 @@ def build(force=False, verbose=True, sources=None, lib=None, extra_flags=()):
     lib = lib or LIB
     os.makedirs(OBJ, exist_ok=True)
     os.makedirs(os.path.dirname(lib), exist_ok=True)
-    headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
+    headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".h", ".inc"))]
     headers.append(os.path.join(ROOT, "include", "zigma_hip.h"))
     jobs = []
     objs = []
@@ -43,7 +44,7 @@ def build(force=False, verbose=True, sources=None, lib=None, extra_flags=()):
             print(" ".join(cmd), flush=True)
         subprocess.run(cmd, check=True)
 
-    with ThreadPoolExecutor(max_workers=min(4, max(1, len(jobs)))) as ex:
+    with ThreadPoolExecutor(max_workers=min(8, max(1, len(jobs)))) as ex:
         list(ex.map(run, jobs))
     if force or jobs or _stale(lib, objs):
         run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", lib])

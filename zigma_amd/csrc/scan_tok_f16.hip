@@ -1,0 +1,6 @@
+// Token-major selective-scan kernel, F16 I/O instantiation (see scan_tok.inc).
+#include "scan_tok.inc"
+
+namespace zigma {
+int launch_scan_tok_f16(const zigma_scan_params_t &p, hipStream_t stream) { return launch_tok_io<F16>(p, stream); }
+}  // namespace zigma

@@ -118,214 +118,14 @@ __global__ __launch_bounds__(64) void scan_generic_kernel(const zigma_scan_param
     }
 }
 
-// =================================================================================================
-// token-major kernel
-// =================================================================================================
-
-// lane M (0..15) of every 16-lane row, broadcast to the whole row: DPP row_newbcast (gfx90a+).  With full
-// row/bank masks the compiler folds it into the consuming v_mul_f32 / v_fmac_f32 as a DPP source operand.
-template <int M>
-__device__ __forceinline__ float row_bcast(float v) {
-    return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x150 + M, 0xf, 0xf, true));
-}
-// y += row_bcast<M>(c) * h as ONE v_fmac_f32_dpp (hipcc folds DPP into v_mul but not into the tied-operand
-// fmac).  A VALU write of `c` needs 2 wait states before a DPP read of it and nothing inside an asm statement
-// is padded by the compiler: pass every freshly produced `c` through dpp_settle() once.
-template <int M>
-__device__ __forceinline__ void fmac_bcast(float &y, float c, float h) {
-    asm("v_fmac_f32_dpp %0, %1, %2 row_newbcast:%c3 row_mask:0xf bank_mask:0xf bound_ctrl:1"
-        : "+v"(y) : "v"(c), "v"(h), "i"(M));
-}
-__device__ __forceinline__ void dpp_settle(float &c) { asm volatile("s_nop 1" : "+v"(c)); }
-
-constexpr int kSPW = 4;  // states per wave (one DPP row = 4 steps x 4 states)
-
-template <typename IO, typename BCT, int NW, int LT, bool HAS_Z>
-__global__ __launch_bounds__(64 * NW, (5 * 4) / NW >= 5 ? 5 : 4) void scan_tok_kernel(const zigma_scan_params_t p) {
-    const bool HAS_X = p.x != nullptr;
-    static_assert(LT % NW == 0 && LT % 4 == 0, "tile rows split evenly over the waves, 4-step B/C groups");
-    constexpr int RPT = LT / NW;  // tile rows handled by one wave in the cooperative phases
-    constexpr int NG = LT / 4;    // 4-step groups per tile
-    // [buf][step pair][channel][sp0, du0, sp1, du1]  -> one ds_read_b128 feeds two steps
-    __shared__ __attribute__((aligned(16))) float s_spdu[2][LT / 2][64][4];
-    // per-wave partial y: [wave][step pair][channel][2] -> one ds_write_b64 per two steps
-    __shared__ __attribute__((aligned(16))) float s_y[NW][LT / 2][64][2];
-
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int b = blockIdx.y;
-    const int c = blockIdx.x * 64 + lane;  // channel of this lane
-    const int L = p.seqlen;
-    const int n0 = wave * kSPW;
-
-    float a2[kSPW], h[kSPW];
-#pragma unroll
-    for (int j = 0; j < kSPW; ++j) {
-        a2[j] = reinterpret_cast<const float *>(p.A)[c * p.A_d_stride + (n0 + j) * p.A_dstate_stride] * kLog2e;
-        h[j] = 0.f;
-    }
-    const float Dv = p.D ? reinterpret_cast<const float *>(p.D)[c] : 0.f;
-    const float bias = p.delta_bias ? reinterpret_cast<const float *>(p.delta_bias)[c] : 0.f;
-    const bool sp_on = p.delta_softplus != 0;
-
-    // per-sample base pointers (64-bit, once); inside a sample every offset fits 32 bits (dispatcher checks)
-    using io_t = typename IO::raw;
-    using bc_t = typename BCT::raw;
-    const io_t *up = reinterpret_cast<const io_t *>(p.u) + b * p.u_batch_stride + c;
-    const io_t *dp = reinterpret_cast<const io_t *>(p.delta) + b * p.delta_batch_stride + c;
-    const io_t *zp = reinterpret_cast<const io_t *>(p.z) + b * p.z_batch_stride + c;
-    io_t *op = reinterpret_cast<io_t *>(p.out) + b * p.out_batch_stride + c;
-    io_t *ozp = reinterpret_cast<io_t *>(p.out_z) + b * p.out_z_batch_stride + c;
-    const int u_ls = static_cast<int>(p.u_l_stride), d_ls = static_cast<int>(p.delta_l_stride);
-    const int z_ls = static_cast<int>(p.z_l_stride), o_ls = static_cast<int>(p.out_l_stride);
-    const int oz_ls = static_cast<int>(p.out_z_l_stride);
-    const int B_ls = static_cast<int>(p.B_l_stride), C_ls = static_cast<int>(p.C_l_stride);
-    // B/C group register: lane -> (step s = (lane & 15) >> 2, state j = lane & 3)
-    const int bc_s = (lane & 15) >> 2;
-    const bc_t *Bp = reinterpret_cast<const bc_t *>(p.B) + b * p.B_batch_stride + (n0 + (lane & 3)) * p.B_dstate_stride;
-    const bc_t *Cp = reinterpret_cast<const bc_t *>(p.C) + b * p.C_batch_stride + (n0 + (lane & 3)) * p.C_dstate_stride;
-    const int chunk_len = p.chunk_len > 0 ? p.chunk_len : 2048;
-    const int n_chunks = (L + chunk_len - 1) / chunk_len;
-    float cum = 0.f;
-
-    struct Rows { float u[RPT], d[RPT], z[RPT]; };   // this wave's rows of one tile
-    struct BC { typename BCT::raw b[NG], c[NG]; };   // this wave's B/C of one tile
-    Rows ra, rb;
-    BC ba, bb;
-
-    auto issue_loads = [&](int t, Rows &rw, BC &bc) {
-#pragma unroll
-        for (int i = 0; i < RPT; ++i) {
-            const int k = t * LT + wave * RPT + i;
-            const bool ok = k < L;
-            const int kk = ok ? k : L - 1;
-            rw.u[i] = to_float<IO>(up[kk * u_ls]);
-            rw.d[i] = to_float<IO>(dp[kk * d_ls]);
-            if constexpr (HAS_Z) {
-                const int zrow = p.z_row_index ? p.z_row_index[kk] : kk;
-                rw.z[i] = to_float<IO>(zp[zrow * z_ls]);
-            }
-            if (!ok) { rw.u[i] = 0.f; rw.d[i] = 0.f; }
-        }
-#pragma unroll
-        for (int g = 0; g < NG; ++g) {
-            int k = t * LT + g * 4 + bc_s;
-            if (k >= L) k = L - 1;  // padded steps carry du = 0
-            bc.b[g] = Bp[k * B_ls];
-            bc.c[g] = Cp[k * C_ls];
-        }
-    };
-    // cooperative prologue of tile t: softplus, delta*u -> LDS
-    auto stage = [&](int t, const Rows &rw) {
-#pragma unroll
-        for (int i = 0; i < RPT; ++i) {
-            const int r = wave * RPT + i;
-            const int k = t * LT + r;
-            float dv = rw.d[i] + bias;
-            if (sp_on) dv = softplus20(dv);
-            if (k >= L) dv = 0.f;  // identity step: a = 1, b = 0 (h and cum stay put)
-            const float du = dv * rw.u[i];
-            v2f w = {dv, du};
-            *reinterpret_cast<v2f *>(&s_spdu[t & 1][r >> 1][lane][(r & 1) * 2]) = w;
-        }
-    };
-
-    const int n_tiles = (L + LT - 1) / LT;
-
-    // one step of the recurrence for this lane's 4 states; S = step inside the 4-step group
-#define ZIGMA_STEP(S, dv, du, Bf, Cf, yv)                                        \
-    {                                                                            \
-        const float e0 = fast_exp2((dv) * a2[0]), e1 = fast_exp2((dv) * a2[1]);  \
-        const float e2 = fast_exp2((dv) * a2[2]), e3 = fast_exp2((dv) * a2[3]);  \
-        h[0] = __builtin_fmaf(e0, h[0], row_bcast<(S) * 4 + 0>(Bf) * (du));      \
-        h[1] = __builtin_fmaf(e1, h[1], row_bcast<(S) * 4 + 1>(Bf) * (du));      \
-        h[2] = __builtin_fmaf(e2, h[2], row_bcast<(S) * 4 + 2>(Bf) * (du));      \
-        h[3] = __builtin_fmaf(e3, h[3], row_bcast<(S) * 4 + 3>(Bf) * (du));      \
-        yv = 0.f;                                                                \
-        fmac_bcast<(S) * 4 + 0>(yv, Cf, h[0]);                                   \
-        fmac_bcast<(S) * 4 + 1>(yv, Cf, h[1]);                                   \
-        fmac_bcast<(S) * 4 + 2>(yv, Cf, h[2]);                                   \
-        fmac_bcast<(S) * 4 + 3>(yv, Cf, h[3]);                                   \
-    }
-
-    // one tile: prefetch rows of t+1 -> recurrence over t -> stage t+1 -> barrier -> epilogue of t
-    auto tile = [&](int t, Rows &cur, Rows &nxt, const BC &bcur, BC &bnxt) {
-        const int s = t & 1;
-        if (t + 1 < n_tiles) issue_loads(t + 1, nxt, bnxt);
-
-#pragma unroll
-        for (int g = 0; g < NG; ++g) {
-            const float Bf = to_float<BCT>(bcur.b[g]);
-            float Cf = to_float<BCT>(bcur.c[g]);
-            dpp_settle(Cf);
-            const v4f q0 = *reinterpret_cast<const v4f *>(&s_spdu[s][g * 2][lane][0]);
-            const v4f q1 = *reinterpret_cast<const v4f *>(&s_spdu[s][g * 2 + 1][lane][0]);
-            float y0, y1, y2, y3;
-            ZIGMA_STEP(0, q0.x, q0.y, Bf, Cf, y0)
-            ZIGMA_STEP(1, q0.z, q0.w, Bf, Cf, y1)
-            *reinterpret_cast<v2f *>(&s_y[wave][g * 2][lane][0]) = v2f{y0, y1};
-            ZIGMA_STEP(2, q1.x, q1.y, Bf, Cf, y2)
-            ZIGMA_STEP(3, q1.z, q1.w, Bf, Cf, y3)
-            *reinterpret_cast<v2f *>(&s_y[wave][g * 2 + 1][lane][0]) = v2f{y2, y3};
-            if (HAS_X) cum += (q0.x + q0.z) + (q1.x + q1.z);
-        }
-        if (HAS_X) {
-            // carries at chunk ends.  chunk_len is a multiple of LT (dispatcher), so a chunk end is a tile end;
-            // the sequence end may fall inside the last tile, whose padded steps are identities.
-            const int64_t k_next = (static_cast<int64_t>(t) + 1) * LT;
-            if (t == n_tiles - 1 || k_next % chunk_len == 0) {
-                const int64_t k_eff = (k_next <= L ? k_next : L) - 1;
-                float *xr = reinterpret_cast<float *>(p.x) +
-                            ((static_cast<int64_t>(b) * p.dim + c) * n_chunks + k_eff / chunk_len) * 2 * p.dstate;
-#pragma unroll
-                for (int j = 0; j < kSPW; ++j) {
-                    xr[2 * (n0 + j)] = fast_exp2(cum * a2[j]);
-                    xr[2 * (n0 + j) + 1] = h[j];
-                }
-            }
-        }
-        if (t + 1 < n_tiles) stage(t + 1, nxt);
-        __syncthreads();
-
-        // ---- cooperative epilogue of tile t: sum the partial y, skip term, gate, store --------
-#pragma unroll
-        for (int i = 0; i < RPT; ++i) {
-            const int r = wave * RPT + i;
-            const int k = t * LT + r;
-            if (k < L) {
-                float y = Dv * cur.u[i];
-#pragma unroll
-                for (int w = 0; w < NW; ++w) y += s_y[w][r >> 1][lane][r & 1];
-                const int orow = p.out_row_index ? p.out_row_index[k] : k;
-                if (p.out) op[orow * o_ls] = from_float<IO>(y);
-                if constexpr (HAS_Z) ozp[orow * oz_ls] = from_float<IO>(y * silu(cur.z[i]));
-            }
-        }
-        __syncthreads();
-    };
-#undef ZIGMA_STEP
-
-    issue_loads(0, ra, ba);
-    stage(0, ra);
-    __syncthreads();
-    for (int t = 0; t < n_tiles; t += 2) {
-        tile(t, ra, rb, ba, bb);
-        if (t + 1 < n_tiles) tile(t + 1, rb, ra, bb, ba);
-    }
-}
+// token-major kernel: scan_tok.inc, instantiated per I/O element type in scan_tok_{bf16,f16,f32}.hip
+int launch_scan_tok_bf16(const zigma_scan_params_t &p, hipStream_t stream);
+int launch_scan_tok_f16(const zigma_scan_params_t &p, hipStream_t stream);
+int launch_scan_tok_f32(const zigma_scan_params_t &p, hipStream_t stream);
 
 // =================================================================================================
 // host dispatch
 // =================================================================================================
-template <typename IO, typename BCT, int NW, int LT>
-static int launch_tok(const zigma_scan_params_t &p, hipStream_t stream, const char *name) {
-    dim3 grid(p.dim / 64, p.batch), block(64 * NW);
-    if (p.z != nullptr) hipLaunchKernelGGL((scan_tok_kernel<IO, BCT, NW, LT, true>), grid, block, 0, stream, p);
-    else hipLaunchKernelGGL((scan_tok_kernel<IO, BCT, NW, LT, false>), grid, block, 0, stream, p);
-    set_last_kernel(name);
-    return check_launch();
-}
-
 template <typename IO, typename BCT>
 static int launch_generic(const zigma_scan_params_t &p, hipStream_t stream) {
     const int N = p.dstate;
@@ -362,7 +162,7 @@ static bool tok_eligible(const zigma_scan_params_t &p) {
     if (p.x && chunk_len % 16 != 0) return false;  // carries are stored at tile ends
     if (p.bc_dtype != p.io_dtype) return false;    // instantiation set: B/C in the activation dtype
     // in-sample offsets are 32-bit in the kernel
-    const int64_t lim = (int64_t(1) << 31) - 1, Lm = p.seqlen;
+    const int64_t lim = ((int64_t(1) << 31) - 1) / 4, Lm = p.seqlen;  // byte offsets, up to 4-byte elements
     const int64_t ls[] = {p.u_l_stride, p.delta_l_stride, p.z ? p.z_l_stride : 0, p.out ? p.out_l_stride : 0,
                           p.z ? p.out_z_l_stride : 0, p.B_l_stride, p.C_l_stride};
     for (int64_t s : ls)
@@ -388,10 +188,12 @@ extern "C" int zigma_selective_scan_fwd(const zigma_scan_params_t *pp, void *str
     if (!p.z && !p.out) return ZIGMA_ERR_NULL;
 
     if (tok_eligible(p)) {
-        ZIGMA_DISPATCH_DTYPE(p.io_dtype, IO, {
-            if (p.dstate == 16) return launch_tok<IO, IO, 4, 16>(p, stream, "scan_tok_n16");
-            return launch_tok<IO, IO, 2, 16>(p, stream, "scan_tok_n8");
-        })
+        switch (p.io_dtype) {
+            case ZIGMA_BF16: return launch_scan_tok_bf16(p, stream);
+            case ZIGMA_F16: return launch_scan_tok_f16(p, stream);
+            case ZIGMA_F32: return launch_scan_tok_f32(p, stream);
+            default: return ZIGMA_ERR_DTYPE;
+        }
     }
     ZIGMA_DISPATCH_DTYPE(p.io_dtype, IO, {
         ZIGMA_DISPATCH_DTYPE(p.bc_dtype, BCT, { return launch_generic<IO, BCT>(p, stream); })
