@@ -1,0 +1,20 @@
+#!/bin/bash
+# PMC counters for the scan kernel alone (separate passes; no trace domains combined with --pmc).
+R=${GRAFT_REPO_ROOT:-$PWD}
+cd /tmp && export TMPDIR=/tmp
+for pass in "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY" \
+            "SQ_ACTIVE_INST_ANY SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_SCA SQ_INSTS_SMEM SQ_INSTS_VMEM GRBM_GUI_ACTIVE" \
+            "FETCH_SIZE" "WRITE_SIZE"; do
+  tag=$(echo $pass | cut -d' ' -f1)
+  SCAN_ONLY=1 timeout 300 rocprofv3 --pmc $pass --output-format csv -d $R/gpurun_out/pmc_$tag -o pmc -- python $R/tools/bench_kernels.py > $R/gpurun_out/pmc_$tag.log 2>&1
+done
+cd $R
+python - <<'PY'
+import csv, glob, collections
+for f in sorted(glob.glob("gpurun_out/pmc_*/**/*counter_collection.csv", recursive=True)):
+    agg=collections.defaultdict(list)
+    for r in csv.DictReader(open(f)):
+        if "scan_tok" in r["Kernel_Name"]:
+            agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
+    for k,v in agg.items(): print(f"{k:28s} n={len(v):3d} mean={sum(v)/len(v):.4g}")
+PY

@@ -25,11 +25,12 @@ def main():
     st = torch.cuda.current_stream().cuda_stream
     names = {0: "exp2 x8", 1: "pk_fma x8", 2: "fma x8", 3: "mix 8 exp + 16 pk_fma (one wave)",
              4: "split waves: even exp x8 / odd pk_fma x16", 5: "soft exp2 (pk) x16 values", 6: "log2 x8", 7: "rcp x8",
-             8: "mix 8 exp + 16 scalar fma"}
+             8: "mix 8 exp + 16 scalar fma", 9: "mul_dpp row_newbcast x8", 10: "fmac_dpp row_newbcast x8",
+             11: "scan core replica: 2 steps x 4 states (40 VALU incl 8 exp)"}
     clk = 2.4e9
     res = {}
     iters = 4000
-    for wpc in (1, 2, 4):           # 256-thread blocks per CU -> waves per SIMD
+    for wpc in (1, 2, 4, 5):           # 256-thread blocks per CU -> waves per SIMD
         blocks = 256 * wpc
         for mode in names:
             for _ in range(2):

@@ -91,6 +91,39 @@ __global__ __launch_bounds__(256) void k_rate(float *out, int iters, float seed)
         }
         ITER_BODY_END
     }
+    else if (MODE == 9) {  // v_mul_f32 with a DPP row_newbcast source, 8 independent
+        ITER_BODY_BEGIN
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+            x[i] = __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(x[i]), 0x150 + 3, 0xf, 0xf, true)) * 0.999f;
+        ITER_BODY_END
+    } else if (MODE == 10) {  // v_fmac_f32_dpp, 8 independent accumulators
+        ITER_BODY_BEGIN
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+            asm volatile("v_fmac_f32_dpp %0, %1, %2 row_newbcast:5 row_mask:0xf bank_mask:0xf bound_ctrl:1" : "+v"(x[i]) : "v"(p[i].x), "v"(p[i].y));
+        ITER_BODY_END
+    } else if (MODE == 11) {  // replica of the scan core: 2 steps x 4 states = 8 x (mul, exp, mul_dpp, fma, fmac_dpp)
+        float hh[4] = {x[0], x[1], x[2], x[3]}, aa[4] = {-x[4], -x[5], -x[6], -x[7]};
+        float Bf = p[0].x, Cf = p[0].y, dv = p[1].x, du = p[1].y, y = 0.f;
+        ITER_BODY_BEGIN
+#pragma unroll
+        for (int st = 0; st < 2; ++st) {
+            float yy;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float e = __builtin_amdgcn_exp2f(dv * aa[j]);
+                const float bq = __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(Bf), 0x150 + 2, 0xf, 0xf, true)) * du;
+                hh[j] = __builtin_fmaf(e, hh[j], bq);
+                if (j == 0) yy = __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(Cf), 0x150 + 1, 0xf, 0xf, true)) * hh[0];
+                else asm volatile("v_fmac_f32_dpp %0, %1, %2 row_newbcast:5 row_mask:0xf bank_mask:0xf bound_ctrl:1" : "+v"(yy) : "v"(Cf), "v"(hh[j]));
+            }
+            y += yy;
+            dv += 1e-9f;
+        }
+        ITER_BODY_END
+        x[0] = hh[0] + y; x[1] = hh[1]; x[2] = hh[2]; x[3] = hh[3];
+    }
     float s = 0.f;
 #pragma unroll
     for (int i = 0; i < 8; ++i) s += x[i] + p[i].x + p[i].y;
@@ -110,6 +143,9 @@ extern "C" int ubench_launch(int mode, int blocks, int iters, float *out, void *
         case 6: hipLaunchKernelGGL(k_rate<6>, g, b, 0, st, out, iters, 0.5f); break;
         case 7: hipLaunchKernelGGL(k_rate<7>, g, b, 0, st, out, iters, 0.5f); break;
         case 8: hipLaunchKernelGGL(k_rate<8>, g, b, 0, st, out, iters, 0.5f); break;
+        case 9: hipLaunchKernelGGL(k_rate<9>, g, b, 0, st, out, iters, 0.5f); break;
+        case 10: hipLaunchKernelGGL(k_rate<10>, g, b, 0, st, out, iters, 0.5f); break;
+        case 11: hipLaunchKernelGGL(k_rate<11>, g, b, 0, st, out, iters, 0.5f); break;
         default: return -1;
     }
     return hipGetLastError() == hipSuccess ? 0 : -5;
