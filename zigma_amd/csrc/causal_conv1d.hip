@@ -43,53 +43,92 @@ template <> __device__ __forceinline__ uint4 pack4<F32>(const float (&f)[4]) {
     return make_uint4(__float_as_uint(f[0]), __float_as_uint(f[1]), __float_as_uint(f[2]), __float_as_uint(f[3]));
 }
 
-// grid: (ceil(dim / (4*64)), ceil(L / LT), batch); block 64.
+// grid: (ceil(dim / (4*64)), ceil(L / LT), batch); block 64.  A lane owns 4 adjacent channels and LT consecutive
+// scan positions.  All LT + W - 1 row loads of the tile are issued before the first FMA (memory-level
+// parallelism is what an HBM-bound kernel needs); rows are addressed as buffer descriptor + fixed lane offset +
+// scalar row offset, the row table arrives through one vector load and v_readlane.
+using rsrc_t = __amdgpu_buffer_rsrc_t;
+template <typename IO> __device__ __forceinline__ typename Pack<IO, 4>::type buf_ld4(rsrc_t r, unsigned voff, int soff) {
+    if constexpr (sizeof(typename IO::raw) == 2) {
+        const auto v = __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0);
+        return make_uint2(v[0], v[1]);
+    } else {
+        const auto v = __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0);
+        return make_uint4(v[0], v[1], v[2], v[3]);
+    }
+}
+template <typename IO> __device__ __forceinline__ void buf_st4(const typename Pack<IO, 4>::type &v, rsrc_t r, unsigned voff, int soff) {
+    typedef unsigned u2 __attribute__((ext_vector_type(2)));
+    typedef unsigned u4 __attribute__((ext_vector_type(4)));
+    if constexpr (sizeof(typename IO::raw) == 2) __builtin_amdgcn_raw_buffer_store_b64(u2{v.x, v.y}, r, voff, soff, 0);
+    else __builtin_amdgcn_raw_buffer_store_b128(u4{v.x, v.y, v.z, v.w}, r, voff, soff, 0);
+}
+
 template <typename IO, typename WT, int W, int LT, bool SILU>
 __global__ __launch_bounds__(64) void conv_tok_kernel(const zigma_conv_params_t p) {
     using P = typename Pack<IO, 4>::type;
-    const int c0 = (blockIdx.x * 64 + threadIdx.x) * 4;
-    if (c0 >= p.dim) return;
+    constexpr int ES = static_cast<int>(sizeof(typename IO::raw)), NR = LT + W - 1;
+    static_assert(NR <= 64, "row table of a tile must fit one wave");
+    const int lane = threadIdx.x;
+    const int c0 = (blockIdx.x * 64 + lane) * 4;
     const int b = blockIdx.z;
     const int k0 = blockIdx.y * LT;
     const int L = p.seqlen;
+    const bool live = c0 < p.dim;          // dead lanes keep running (readlane needs the whole wave), re-read channel 0, never store
+    const int cc = live ? c0 : 0;
 
     float w[4][W], bias[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
 #pragma unroll
-        for (int j = 0; j < W; ++j) w[i][j] = ld<WT>(p.weight, (c0 + i) * p.weight_c_stride + j * p.weight_width_stride);
-        bias[i] = p.bias ? ld<WT>(p.bias, c0 + i) : 0.f;
+        for (int j = 0; j < W; ++j) w[i][j] = ld<WT>(p.weight, (cc + i) * p.weight_c_stride + j * p.weight_width_stride);
+        bias[i] = p.bias ? ld<WT>(p.bias, cc + i) : 0.f;
     }
-    const char *xb = reinterpret_cast<const char *>(p.x) + (b * p.x_batch_stride + c0) * sizeof(typename IO::raw);
-    char *ob = reinterpret_cast<char *>(p.out) + (b * p.out_batch_stride + c0) * sizeof(typename IO::raw);
-    const int64_t xls = p.x_l_stride * sizeof(typename IO::raw), ols = p.out_l_stride * sizeof(typename IO::raw);
+    const int64_t span = static_cast<int64_t>(L - 1);
+    const int x_ls = static_cast<int>(p.x_l_stride) * ES, o_ls = static_cast<int>(p.out_l_stride) * ES;
+    const rsrc_t x_rs = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<typename IO::raw *>(reinterpret_cast<const typename IO::raw *>(p.x) + b * p.x_batch_stride), 0,
+        static_cast<int>(span * x_ls + static_cast<int64_t>(p.dim) * ES), 0x00020000);
+    const rsrc_t o_rs = __builtin_amdgcn_make_buffer_rsrc(
+        reinterpret_cast<typename IO::raw *>(p.out) + b * p.out_batch_stride, 0,
+        static_cast<int>(span * o_ls + static_cast<int64_t>(p.dim) * ES), 0x00020000);
+    const unsigned lane_off = static_cast<unsigned>(cc) * ES;
 
-    auto row = [&](int k) -> P {  // scan position k (may be < 0: zero padding)
-        if (k < 0) return P{};
-        const int64_t r = p.x_row_index ? p.x_row_index[k] : k;
-        return *reinterpret_cast<const P *>(xb + r * xls);
-    };
-    float win[W][4];  // win[j] = x'[k - (W-1) + j]
+    // row table entries of this tile: lane i <- input row of scan position k0 - (W-1) + i
+    int rowv;
+    {
+        int k = k0 - (W - 1) + lane;
+        k = k < 0 ? 0 : (k < L ? k : L - 1);
+        rowv = p.x_row_index ? p.x_row_index[k] : k;
+    }
+    P raw[NR];
 #pragma unroll
-    for (int j = 0; j < W - 1; ++j) unpack4<IO>(row(k0 - (W - 1) + j), win[j]);
-
-    const int kend = min(k0 + LT, L);
-#pragma unroll 4
-    for (int k = k0; k < kend; ++k) {
-        unpack4<IO>(row(k), win[W - 1]);
-        float o[4];
+    for (int i = 0; i < NR; ++i) {
+        const int k = k0 - (W - 1) + i;                       // wave-uniform
+        const int row = __builtin_amdgcn_readlane(rowv, i);
+        raw[i] = P{};
+        if (k >= 0 && k < L) raw[i] = buf_ld4<IO>(x_rs, lane_off, row * x_ls);   // zero left padding otherwise
+    }
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            float acc = bias[i];
+    for (int j = 0; j < LT; ++j) {
+        const int k = k0 + j;
+        if (k < L) {
+            float o[4];
 #pragma unroll
-            for (int j = 0; j < W; ++j) acc += w[i][j] * win[j][i];
-            o[i] = SILU ? silu(acc) : acc;
+            for (int i = 0; i < 4; ++i) o[i] = bias[i];
+#pragma unroll
+            for (int t = 0; t < W; ++t) {
+                float xin[4];
+                unpack4<IO>(raw[j + t], xin);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) o[i] += w[i][t] * xin[i];
+            }
+            if (SILU) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) o[i] = silu(o[i]);
+            }
+            if (live) buf_st4<IO>(pack4<IO>(o), o_rs, lane_off, k * o_ls);
         }
-        *reinterpret_cast<P *>(ob + k * ols) = pack4<IO>(o);
-#pragma unroll
-        for (int j = 0; j < W - 1; ++j)
-#pragma unroll
-            for (int i = 0; i < 4; ++i) win[j][i] = win[j + 1][i];
     }
 }
 
@@ -121,9 +160,12 @@ static int launch_conv(const zigma_conv_params_t &p, hipStream_t stream) {
     constexpr size_t es = sizeof(typename IO::raw);
     const bool tok = p.x_c_stride == 1 && p.out_c_stride == 1 && p.dim % 4 == 0 &&
                      reinterpret_cast<uintptr_t>(p.x) % (4 * es) == 0 && reinterpret_cast<uintptr_t>(p.out) % (4 * es) == 0 &&
-                     p.x_l_stride % 4 == 0 && p.out_l_stride % 4 == 0 && p.x_batch_stride % 4 == 0 && p.out_batch_stride % 4 == 0;
+                     p.x_l_stride % 4 == 0 && p.out_l_stride % 4 == 0 && p.x_batch_stride % 4 == 0 && p.out_batch_stride % 4 == 0 &&
+                     p.x_l_stride >= 0 && p.out_l_stride >= 0 &&
+                     (p.x_l_stride * p.seqlen + p.dim) * static_cast<int64_t>(es) < (int64_t(1) << 31) &&
+                     (p.out_l_stride * p.seqlen + p.dim) * static_cast<int64_t>(es) < (int64_t(1) << 31);
     if (tok) {
-        constexpr int LT = 32;
+        constexpr int LT = 16;
         dim3 grid((p.dim / 4 + 63) / 64, (p.seqlen + LT - 1) / LT, p.batch), block(64);
 #define ZIGMA_CONV_TOK(W_)                                                                                          \
     if (p.silu_activation) hipLaunchKernelGGL((conv_tok_kernel<IO, WT, W_, LT, true>), grid, block, 0, stream, p);  \

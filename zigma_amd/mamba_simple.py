@@ -117,6 +117,7 @@ class Mamba(nn.Module):
             out_rows = _int32_table(inv, device)
         self.register_buffer("_out_rows", out_rows, persistent=False)
         self._rev_cache = {}
+        self._const_cache = {}
 
     def _s4d_real_log(self, device):
         A = torch.arange(1, self.d_state + 1, dtype=torch.float32, device=device).repeat(self.d_inner, 1).contiguous()
@@ -141,6 +142,21 @@ class Mamba(nn.Module):
     def forward(self, hidden_states, inference_params=None):
         return self._mamba_inner_forward(hidden_states, inference_params)
 
+    def _scan_consts(self, sfx):
+        """(A = -exp(A_log), D, dt_bias) in float32, as the reference passes them to the scan
+        (mamba_simple.py:298,383-384).  They only change when the parameters do, so they are cached against the
+        parameters' version counters instead of being recomputed by three eager kernels per layer per forward."""
+        A_log, D, dtb = getattr(self, "A" + sfx + "_log"), getattr(self, "D" + sfx), getattr(self, "dt_proj" + sfx).bias
+        key = (A_log._version, D._version, dtb._version, A_log.data_ptr(), D.data_ptr(), dtb.data_ptr())
+        hit = self._const_cache.get(sfx)
+        if hit is None or hit[0] != key or torch.is_grad_enabled():
+            vals = (-torch.exp(A_log.float()), D.float(), dtb.float())
+            if torch.is_grad_enabled():
+                return vals
+            hit = (key, vals)
+            self._const_cache[sfx] = hit
+        return hit[1]
+
     def _reversed_table(self, L, device):
         key = (L, str(device))
         if key not in self._rev_cache:
@@ -153,19 +169,19 @@ class Mamba(nn.Module):
             raise NotImplementedError("zigma_amd: recurrent decoding is out of scope (ZigMa never passes inference_params)")
         batch, seqlen, _ = hidden_states.shape
         xz = F.linear(hidden_states, self.in_proj.weight, self.in_proj.bias)          # (B, L, 2*Di) token-major
-        A = -torch.exp(self.A_log.float())
+        A, Dp, dtb = self._scan_consts("")
         fwd = lambda t, perm: mamba_inner_tok(t, self.conv1d.weight, self.conv1d.bias, self.x_proj.weight,
-                                               self.dt_proj.weight, A, self.D.float(), self.dt_proj.bias.float(),
+                                               self.dt_proj.weight, A, Dp, dtb,
                                                perm=perm, out_rows=self._out_rows if perm is self._perm else None,
                                                delta_softplus=True)
         st = self.scan_type
         if st == "v1":
             y = fwd(xz, None)
         elif st == "v2":
-            A_b = -torch.exp(self.A_b_log.float())
+            A_b, Dp_b, dtb_b = self._scan_consts("_b")
             y = fwd(xz, None)
             y_b = mamba_inner_tok(xz, self.conv1d_b.weight, self.conv1d_b.bias, self.x_proj_b.weight,
-                                  self.dt_proj_b.weight, A_b, self.D_b.float(), self.dt_proj_b.bias.float(),
+                                  self.dt_proj_b.weight, A_b, Dp_b, dtb_b,
                                   perm=self._reversed_table(seqlen, xz.device), delta_softplus=True)
             y = y + y_b                                   # both already in token order
         elif st.startswith(("zigzagN", "hilbertN", "randomN")):
