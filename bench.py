@@ -65,6 +65,20 @@ class ScanTimer:
         return sum(a.elapsed_time(b) for a, b in self.pairs) / max(len(self.pairs), 1)
 
 
+def pmc_traffic():
+    """HBM bytes per scan launch from the committed rocprofv3 PMC passes (profiles/*pmc_scan*.json written by
+    tools/pmc_scan.sh; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950), or None."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_scan*.json")))
+    if not files:
+        return None
+    try:
+        d = json.load(open(files[-1]))
+        return d.get("hbm_bytes_per_launch")
+    except Exception:
+        return None
+
+
 def build_model(cfg, device, dtype, seed=0):
     from zigma_amd.model_zigma import ZigMa
     torch.manual_seed(seed)
@@ -129,20 +143,18 @@ def main():
     ap.add_argument("--no-scan-events", action="store_true")
     args = ap.parse_args()
 
-    rank = int(os.environ.get("RANK", 0))
-    world = int(os.environ.get("WORLD_SIZE", 1))
-    local_rank = int(os.environ.get("LOCAL_RANK", 0))
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    from zigma_amd import sharded_sampling as ss
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
+    local_rank = int(os.environ.get("LOCAL_RANK", 0))
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
+    rank, world, _ = ss.init_from_env(backend="nccl", device=device)
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     dist = None
     if world > 1:
         import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
 
     wl = WORKLOADS[args.workload]
     batch = args.batch or wl["batch"]
@@ -158,30 +170,14 @@ def main():
         with torch.no_grad():
             v = model(x, t, y)
         if world > 1:
-            dist.all_gather_into_tensor(gathered, v.contiguous())
+            ss.gather_samples(v, world, out=gathered)
         return v
 
-    for _ in range(args.warmup):
+    for _ in range(args.warmup):          # scan-event timing only inside the timed region
         step()
     timer.enabled = not args.no_scan_events
-
-    def fence():
-        torch.cuda.synchronize(device)
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize(device)
-
-    fence()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    fence()
-    elapsed = time.perf_counter() - t0
+    elapsed = ss.timed_steps(step, args.steps, 0, device, world)
     timer.enabled = False
-    el = torch.tensor([elapsed], device=device, dtype=torch.float64)
-    if world > 1:
-        dist.all_reduce(el, op=dist.ReduceOp.MAX)
-    elapsed = float(el.item())
 
     if rank == 0:
         from zigma_amd import _lib
@@ -192,7 +188,7 @@ def main():
             ms = timer.mean_ms()
             ach = algo_bytes / (ms * 1e-3)
             roof = dict(bound="hbm", kernel="scan_tok (fused zigzag selective scan)", achieved=ach / 1e9,
-                        peak=HBM_PEAK / 1e9, unit="GB/s", frac=ach / HBM_PEAK, traffic=None,
+                        peak=HBM_PEAK / 1e9, unit="GB/s", frac=ach / HBM_PEAK, traffic=pmc_traffic(),
                         launch_us=ms * 1e3, launches=len(timer.pairs), algorithmic_bytes=algo_bytes)
         line = dict(metric="denoiser-forward latents/sec (BxL tokens/s), ZigMa d=640 L=32^2",
                     value=world * batch * L * args.steps / elapsed, unit="tokens/s", n_gpus=world, steps=args.steps,

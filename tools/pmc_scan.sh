@@ -16,5 +16,5 @@ for f in sorted(glob.glob("gpurun_out/pmc_*/**/*counter_collection.csv", recursi
     for r in csv.DictReader(open(f)):
         if "scan_tok" in r["Kernel_Name"]:
             agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
-    for k,v in agg.items(): print(f"{k:28s} n={len(v):3d} mean={sum(v)/len(v):.4g}")
+    for k,v in agg.items(): print(f"{k:28s} n={len(v):3d} mean={sum(v)/len(v):.6g}")
 PY
