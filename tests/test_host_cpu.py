@@ -192,3 +192,37 @@ def test_module_plumbing_with_oracle_standins(name, monkeypatch):
     with torch.no_grad():
         out = m(torch.from_numpy(g["x"]), torch.from_numpy(g["t"]), y)
     assert rel_err(out.numpy(), g["out"]) < 2e-5, rel_err(out.numpy(), g["out"])
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference"), reason="needs the reference checkout (build container only)")
+def test_extension_shims_under_the_reference_python(monkeypatch):
+    """the reference's OWN `mamba_inner_fn` (MambaInnerFn.forward) runs on the shim modules.
+    Kernels are replaced by the oracle stand-ins here (CPU); what is checked is the call surface — argument
+    order, views/strides the reference passes, allocation conventions, return arity."""
+    import importlib
+    import sys
+    import types
+    import kernel_standins
+    kernel_standins.install(monkeypatch)
+    from zigma_amd import _lib, extension_shims
+    monkeypatch.setattr(_lib, "require_device", lambda *a: torch.device("cpu"))
+    for name in ("selective_scan_cuda", "causal_conv1d_cuda"):
+        monkeypatch.delitem(sys.modules, name, raising=False)
+    ss, cc = extension_shims.install()
+    monkeypatch.syspath_prepend("/root/reference/dis_causal_conv1d")
+    for pkg, path in (("dis_mamba", "/root/reference/dis_mamba"), ("dis_mamba.mamba_ssm", "/root/reference/dis_mamba/mamba_ssm"),
+                      ("dis_mamba.mamba_ssm.ops", "/root/reference/dis_mamba/mamba_ssm/ops")):
+        m = types.ModuleType(pkg)
+        m.__path__ = [path]
+        monkeypatch.setitem(sys.modules, pkg, m)
+    for name in ("causal_conv1d", "causal_conv1d.causal_conv1d_interface", "dis_mamba.mamba_ssm.ops.selective_scan_interface"):
+        monkeypatch.delitem(sys.modules, name, raising=False)
+    ssi = importlib.import_module("dis_mamba.mamba_ssm.ops.selective_scan_interface")
+    assert ssi.selective_scan_cuda is ss and ssi.causal_conv1d_cuda is cc
+    g = load_golden("mamba_inner.npz")
+    T = lambda k: torch.from_numpy(g[k])
+    with torch.no_grad():
+        out = ssi.mamba_inner_fn(T("xz"), T("conv_w"), T("conv_b"), T("x_proj_w"), T("dt_proj_w"), T("out_proj_w"),
+                                 T("out_proj_b"), T("A"), None, None, T("D"), delta_bias=T("delta_bias"),
+                                 delta_softplus=True)
+    assert rel_err(out.numpy(), g["out"]) < 5e-6
