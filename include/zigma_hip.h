@@ -160,6 +160,33 @@ typedef struct zigma_norm_params {
 
 int zigma_add_norm_fwd(const zigma_norm_params_t *p, void *stream);
 
+/* ------------------------------------------------------------------------------------------
+ * dt_proj + bias + softplus on the matrix cores (bf16 in / fp32 accumulate / bf16 out).
+ * Replaces the skinny GEMM  delta = delta_proj_weight @ x_dbl[:, :dt_rank].T  of the reference
+ * (dis_mamba/mamba_ssm/ops/selective_scan_interface.py:323, K = dt_rank) together with the
+ * softplus(delta + delta_bias) its scan kernel applies first (selective_scan_fwd_kernel.cuh:153-156):
+ *
+ *   out[m, d] = act( sum_{r<k} x[m, r] * w[d, r] + bias[d] ),   act = softplus with pass-through above 20
+ *
+ * x: (m, >=k) rows of pitch x_row_stride (the first k columns of x_dbl);  w: (n, k) = dt_proj.weight;
+ * bias: float32 (n) or NULL;  out: (m, n).  The selective scan is then called with delta_softplus = 0 and
+ * delta_bias = NULL.  Limits: dtype bf16, k <= 48, n % 64 == 0, x/w rows 16-byte aligned.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct zigma_dtproj_params {
+    int64_t m;              /* tokens (batch * seqlen) */
+    int32_t n, k;           /* d_inner, dt_rank */
+    int32_t dtype;          /* zigma_dtype_t of x, w, out */
+    int32_t softplus;       /* 0: plain affine */
+    int32_t flags;          /* reserved, must be 0 */
+    int32_t pad_;
+    int64_t x_row_stride, w_row_stride, out_row_stride;
+    const void *x, *w;
+    const void *bias;
+    void *out;
+} zigma_dtproj_params_t;
+
+int zigma_dt_proj_softplus_fwd(const zigma_dtproj_params_t *p, void *stream);
+
 /* ------------------------------------------------------------------------------------------ */
 const char *zigma_strerror(int status);
 int zigma_abi_version(void);

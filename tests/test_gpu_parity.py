@@ -270,6 +270,28 @@ def test_norm_vs_golden_and_fused():
     assert rel_err(N(n), bf(n_ref)) < 1e-3 and rel_err(N(ym), bf(ym_ref)) < 1e-3
 
 
+@pytest.mark.parametrize("M,Di,R,S", [(1, 64, 40, 72), (100, 128, 40, 72), (4096, 1280, 40, 72), (333, 192, 5, 40), (64, 64, 48, 48)])
+def test_dt_proj_softplus_mfma_vs_oracle(M, Di, R, S):
+    """out = softplus(x[:, :R] @ W.T + b): fp32 oracle on the same bf16 operands, result rounded to bf16."""
+    from zigma_amd import _lib
+    from zigma_amd.selective_scan_interface import dt_proj_eligible, dt_proj_softplus
+    rng = np.random.default_rng(M + R)
+    x = zo.bf16_round(rng.standard_normal((2, M, S)).astype(np.float32))
+    w = zo.bf16_round((rng.standard_normal((Di, R)) * 0.3).astype(np.float32))
+    b = (rng.standard_normal(Di) * 2).astype(np.float32)
+    b[0] = 25.0                                   # softplus pass-through branch (x > 20)
+    wt = torch.zeros(Di, 48, device=DEV, dtype=torch.bfloat16)[:, :R]
+    wt.copy_(T(w, torch.bfloat16))
+    xt = T(x, torch.bfloat16)
+    assert dt_proj_eligible(xt, R, wt)
+    out = dt_proj_softplus(xt, R, wt, T(b), True)
+    assert _lib.last_kernel() == "dt_proj_softplus_mfma" and out.shape == (2, M, Di)
+    ref = zo.bf16_round(zo.softplus(x[:, :, :R] @ w.T + b))
+    assert np.allclose(N(out), ref, rtol=1e-2, atol=1e-2) and rel_err(N(out), ref) < 1e-3
+    lin = dt_proj_softplus(xt, R, wt, None, False)
+    assert rel_err(N(lin), zo.bf16_round(x[:, :, :R] @ w.T)) < 1e-3
+
+
 # ---------------------------------------------------------------------------------------------------
 # mamba inner + model
 # ---------------------------------------------------------------------------------------------------

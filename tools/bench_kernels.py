@@ -72,6 +72,13 @@ def main():
     by = B * L * E * (2 + 2 + 4 + 4 + 2 + 2)     # x, branch, res in, res out, n, xm
     print(json.dumps(dict(kernel=_lib.last_kernel(), us=t * 1e6, algo_GBps=by / t / 1e9, frac_of_8TBps=by / t / 8e12)))
 
+    from zigma_amd.selective_scan_interface import dt_proj_softplus
+    Wdt48 = torch.zeros(Di, 48, device=dev, dtype=dt)[:, :R]
+    Wdt48.copy_(torch.randn(Di, R, device=dev, dtype=dt) * 0.1)
+    t = timeit(lambda: dt_proj_softplus(xdbl, R, Wdt48, db, True))
+    by = B * L * (Di * 2 + (R + 2 * N) * 2)
+    print(json.dumps(dict(kernel=_lib.last_kernel(), us=t * 1e6, algo_GBps=by / t / 1e9, frac_of_8TBps=by / t / 8e12)))
+
     # library GEMMs of one block, for the whole-forward budget
     Win = torch.randn(2 * Di, E, device=dev, dtype=dt)
     Wx = torch.randn(R + 2 * N, Di, device=dev, dtype=dt)

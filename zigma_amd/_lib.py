@@ -58,7 +58,13 @@ class NormParams(C.Structure):
     )
 
 
-EXPORTS = ("zigma_selective_scan_fwd", "zigma_causal_conv1d_fwd", "zigma_add_norm_fwd", "zigma_strerror",
+class DtProjParams(C.Structure):
+    _fields_ = ([("m", i64), ("n", i32), ("k", i32), ("dtype", i32), ("softplus", i32), ("flags", i32), ("pad_", i32)]
+                + [(n, i64) for n in ("x_row_stride", "w_row_stride", "out_row_stride")]
+                + [(n, vp) for n in ("x", "w", "bias", "out")])
+
+
+EXPORTS = ("zigma_selective_scan_fwd", "zigma_causal_conv1d_fwd", "zigma_add_norm_fwd", "zigma_dt_proj_softplus_fwd", "zigma_strerror",
            "zigma_abi_version", "zigma_last_kernel")
 
 _lib = None
@@ -74,7 +80,7 @@ def lib():
                 "There is no CPU or eager fallback for the HIP ops.")
         L = C.CDLL(LIB_PATH)
         for name, st in (("zigma_selective_scan_fwd", ScanParams), ("zigma_causal_conv1d_fwd", ConvParams),
-                         ("zigma_add_norm_fwd", NormParams)):
+                         ("zigma_add_norm_fwd", NormParams), ("zigma_dt_proj_softplus_fwd", DtProjParams)):
             fn = getattr(L, name)
             fn.argtypes = [C.POINTER(st), vp]
             fn.restype = C.c_int

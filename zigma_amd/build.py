@@ -1,4 +1,5 @@
 """Build libzigma_hip.so (gfx950) in-tree with hipcc.  `python -m zigma_amd.build [--force]`."""
+import hashlib
 import os
 import subprocess
 import sys
@@ -10,44 +11,63 @@ CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(HERE, "build")
 LIB = os.path.join(HERE, "lib", "libzigma_hip.so")
 SOURCES = ["api.hip", "selective_scan.hip", "scan_tok_bf16.hip", "scan_tok_f16.hip", "scan_tok_f32.hip",
-           "causal_conv1d.hip", "add_norm.hip"]
+           "causal_conv1d.hip", "add_norm.hip", "dt_proj.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=fast", "-fno-slp-vectorize",
          "-I" + os.path.join(ROOT, "include"), "-I" + CSRC]
 
 
-def _stale(target, deps):
-    if not os.path.exists(target):
-        return True
-    t = os.path.getmtime(target)
-    return any(os.path.getmtime(d) > t for d in deps)
+def _digest(paths, extra=()):
+    h = hashlib.sha256()
+    for pth in sorted(paths):
+        h.update(os.path.basename(pth).encode())
+        h.update(open(pth, "rb").read())
+    for e in extra:
+        h.update(str(e).encode())
+    return h.hexdigest()
 
 
 def build(force=False, verbose=True, sources=None, lib=None, extra_flags=()):
+    """Compile every .hip of csrc/ and link the shared library.  Staleness is decided by a CONTENT hash of the
+    sources + flags stored next to the library (mtimes do not survive the snapshot copy to the GPU box, and a
+    library that already matches its sources must not be rebuilt there)."""
     sources = sources or SOURCES
     lib = lib or LIB
     os.makedirs(OBJ, exist_ok=True)
     os.makedirs(os.path.dirname(lib), exist_ok=True)
     headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".h", ".inc"))]
     headers.append(os.path.join(ROOT, "include", "zigma_hip.h"))
-    jobs = []
-    objs = []
-    for src in sources:
-        s = os.path.join(CSRC, src)
-        o = os.path.join(OBJ, src.replace(".hip", ".o"))
-        objs.append(o)
-        if force or _stale(o, [s] + headers):
-            jobs.append([HIPCC, *FLAGS, *extra_flags, "-c", s, "-o", o])
+    stamp = lib + ".srchash"
+    want = _digest([os.path.join(CSRC, s) for s in sources] + headers, extra=list(FLAGS) + list(extra_flags))
+    if not force and os.path.exists(lib) and os.path.exists(stamp) and open(stamp).read().strip() == want:
+        if verbose:
+            print(f"{lib} is up to date (source hash {want[:12]})")
+        return lib
 
     def run(cmd):
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.run(cmd, check=True)
 
+    objs, jobs = [], []
+    for src in sources:
+        s_path = os.path.join(CSRC, src)
+        o_path = os.path.join(OBJ, src.replace(".hip", ".o"))
+        o_stamp = o_path + ".srchash"
+        o_want = _digest([s_path] + headers, extra=list(FLAGS) + list(extra_flags))
+        objs.append(o_path)
+        if force or not os.path.exists(o_path) or not os.path.exists(o_stamp) or open(o_stamp).read().strip() != o_want:
+            jobs.append(([HIPCC, *FLAGS, *extra_flags, "-c", s_path, "-o", o_path], o_stamp, o_want))
+
+    def compile_one(job):
+        cmd, o_stamp, o_want = job
+        run(cmd)
+        open(o_stamp, "w").write(o_want)
+
     with ThreadPoolExecutor(max_workers=min(8, max(1, len(jobs)))) as ex:
-        list(ex.map(run, jobs))
-    if force or jobs or _stale(lib, objs):
-        run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", lib])
+        list(ex.map(compile_one, jobs))
+    run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", lib])
+    open(stamp, "w").write(want)
     return lib
 
 

@@ -129,6 +129,39 @@ def scan_raw(u, delta, A, B, C, D=None, z=None, delta_bias=None, delta_softplus=
     return out, out_z
 
 
+def dt_proj_eligible(x_dbl, dt_rank, weight):
+    """bf16 token-major x_dbl rows / weight rows on 16-byte boundaries, d_inner a multiple of 64, dt_rank <= 48."""
+    return (x_dbl.is_cuda and x_dbl.dtype == torch.bfloat16 and weight.dtype == torch.bfloat16 and dt_rank <= 48
+            and weight.shape[0] % 64 == 0 and x_dbl.stride(-1) == 1 and weight.stride(1) == 1
+            and x_dbl.stride(-2) % 8 == 0 and weight.stride(0) % 8 == 0
+            and x_dbl.data_ptr() % 16 == 0 and weight.data_ptr() % 16 == 0)
+
+
+def dt_proj_softplus(x_dbl, dt_rank, weight, bias=None, softplus=True):
+    """delta' = softplus(x_dbl[..., :dt_rank] @ weight.T + bias) on the matrix cores (zigma_dt_proj_softplus_fwd).
+    x_dbl: (..., >= dt_rank) bf16 rows; weight: (d_inner, dt_rank) bf16; bias: float32 (d_inner) or None.
+    Returns (..., d_inner) bf16.  Fuses reference selective_scan_interface.py:323 with the softplus(delta + bias)
+    at the top of its scan kernel; the scan is then called with delta_softplus=False, delta_bias=None."""
+    dev = _lib.require_device(x_dbl, weight, bias)
+    lead = x_dbl.shape[:-1]
+    x2 = x_dbl.reshape(-1, x_dbl.shape[-1])
+    if x2.stride(-1) != 1:
+        raise RuntimeError("x_dbl rows must be contiguous")
+    n = weight.shape[0]
+    out = torch.empty(x2.shape[0], n, device=x_dbl.device, dtype=x_dbl.dtype)
+    P = _lib.DtProjParams()
+    P.m, P.n, P.k = x2.shape[0], n, dt_rank
+    P.dtype, P.softplus, P.flags = _lib.dtype_id(x_dbl), int(bool(softplus)), 0
+    P.x_row_stride, P.w_row_stride, P.out_row_stride = x2.stride(0), weight.stride(0), out.stride(0)
+    P.x, P.w, P.out = _lib.ptr(x2), _lib.ptr(weight), _lib.ptr(out)
+    if bias is not None:
+        if bias.dtype != torch.float32 or bias.shape != (n,) or bias.stride(0) != 1:
+            raise RuntimeError("bias must be contiguous float32 (d_inner,)")
+        P.bias = _lib.ptr(bias)
+    _lib.call("zigma_dt_proj_softplus_fwd", P, dev)
+    return out.reshape(*lead, n)
+
+
 def selective_scan_cuda_fwd(u, delta, A, B, C, D_, z_, delta_bias_, delta_softplus):
     """Drop-in for the extension entry `selective_scan_cuda.fwd` -> [out, x] (+ [out_z] if z).
     Callee allocates: out = empty_like(delta), x (B, D, ceil(L/2048), 2N) f32, out_z = empty_like(z)."""
@@ -204,7 +237,12 @@ def mamba_inner_tok(xz, conv1d_weight, conv1d_bias, x_proj_weight, delta_proj_we
     u = torch.empty(Bsz, L, Di, device=xz.device, dtype=xz.dtype)
     causal_conv1d_raw(x_half.transpose(1, 2), w, conv1d_bias, True, out=u.transpose(1, 2), x_row_index=perm)
     x_dbl = F.linear(u, x_proj_weight)                               # (B, L, R + 2N)   GEMM
-    delta = F.linear(x_dbl[:, :, :R], delta_proj_weight)             # (B, L, Di)       GEMM
+    fused_dt = delta_softplus and dt_proj_eligible(x_dbl, R, delta_proj_weight)
+    if fused_dt:   # K = dt_rank GEMM + bias + softplus in one write-bound MFMA kernel; scan skips its softplus
+        delta = dt_proj_softplus(x_dbl, R, delta_proj_weight, delta_bias, True)
+        delta_bias, delta_softplus = None, False
+    else:
+        delta = F.linear(x_dbl[:, :, :R], delta_proj_weight)         # (B, L, Di)       GEMM
     Bm, Cm = x_dbl[:, :, R:R + N], x_dbl[:, :, R + N:R + 2 * N]
     if B_proj_bias is not None:
         Bm = Bm + B_proj_bias.to(Bm.dtype)
