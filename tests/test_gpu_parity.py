@@ -400,3 +400,25 @@ def test_empty_inputs():
                             torch.empty(0, 8, 16, device=DEV))
     assert out.shape == (0, 4, 16)
     assert causal_conv1d_fn(u, torch.randn(4, 4, device=DEV)).shape == (0, 4, 16)
+
+
+def test_graphed_forward_matches_eager_and_sampler_runs_on_it():
+    from zigma_amd.graphs import GraphedForward
+    from zigma_amd.transport import Sampler, create_transport
+    m, g, cfg, y = _load_model("zigma_text_zigzag2")
+    x, t = T(g["x"]), T(g["t"])
+    with torch.no_grad():
+        ref = m(x, t, y)
+    gf = GraphedForward(m, x, t, y)
+    out = gf(x, t, y)
+    assert torch.equal(out, ref)
+    x2 = torch.randn_like(x)
+    with torch.no_grad():
+        assert torch.equal(gf(x2, t, y), m(x2, t, y))
+    fn = Sampler(create_transport()).sample_ode(sampling_method="euler", num_steps=4)
+    with torch.no_grad():
+        a = fn(x, gf, y=y)
+        b = fn(x, m.forward, y=y)
+    assert torch.equal(a, b)
+    with pytest.raises(RuntimeError):
+        gf(x[:1], t[:1], y[:1])

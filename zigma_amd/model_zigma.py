@@ -74,12 +74,15 @@ class CrossAttention(nn.Module):
         self.to_v = nn.Linear(context_dim, inner_dim, bias=False)
         self.to_out = nn.Sequential(nn.Linear(inner_dim, query_dim), nn.Dropout(dropout))
 
-    def forward(self, x, text, mask=None):
+    def forward(self, x, text, mask=None, kv=None):
+        """kv: optional precomputed (to_k(text), to_v(text)), each (B, n_ctx, inner) — ZigMa.forward batches these
+        projections of all layers into one GEMM since `text` is the same for every block."""
         Bsz, L, _ = x.shape
         H = self.heads
         q = self.to_q(x).view(Bsz, L, H, -1).transpose(1, 2)
-        k = self.to_k(text).view(Bsz, text.shape[1], H, -1).transpose(1, 2)
-        v = self.to_v(text).view(Bsz, text.shape[1], H, -1).transpose(1, 2)
+        k, v = kv if kv is not None else (self.to_k(text), self.to_v(text))
+        k = k.reshape(Bsz, k.shape[1], H, -1).transpose(1, 2)
+        v = v.reshape(Bsz, v.shape[1], H, -1).transpose(1, 2)
         o = F.scaled_dot_product_attention(q, k, v)
         return self.to_out(o.transpose(1, 2).reshape(Bsz, L, -1))
 
@@ -208,10 +211,12 @@ class Block(nn.Module):
             self.msa = CrossAttention(query_dim=dim, context_dim=dim, heads=8, dim_head=64, dropout=0.0)
             self.norm_msa = nn.LayerNorm(dim, elementwise_affine=False, eps=1e-6)
 
-    def forward_fused(self, pend: Pending, residual, c, text=None):
-        """Hot path.  `pend` is the (unmaterialised) input of this block; returns (Pending, residual)."""
+    def forward_fused(self, pend: Pending, residual, c, text=None, mod=None, kv=None):
+        """Hot path.  `pend` is the (unmaterialised) input of this block; returns (Pending, residual).
+        mod / kv: this block's adaLN modulation rows and cross-attention K/V when the caller has batched them."""
         E = pend.base.shape[-1]
-        mod = self.adaLN_modulation(c)                                        # (B, 3E | 6E)
+        if mod is None:
+            mod = self.adaLN_modulation(c)                                    # (B, 3E | 6E)
         is_rms = isinstance(self.norm, RMSNorm)
         _, residual, n, xm = block_norm(pend.base, self.norm.weight, self.norm.bias, residual, self.norm.eps, is_rms,
                                         residual_in_fp32=self.residual_in_fp32, branch=pend.branch, gate=pend.gate,
@@ -222,7 +227,7 @@ class Block(nn.Module):
         h, _, _, xa = block_norm(n, None, None, None, self.norm_msa.eps, False, residual_in_fp32=False, branch=mix,
                                  gate=mod[:, 2 * E:3 * E], shift=mod[:, 3 * E:4 * E], scale=mod[:, 4 * E:5 * E],
                                  want_x=True, want_y=False, want_res_out=False)
-        att = self.msa(xa, text=text, mask=None)
+        att = self.msa(xa, text=text, mask=None, kv=kv)
         return Pending(h, att, mod[:, 5 * E:6 * E]), residual
 
     def forward(self, x: Tensor, residual: Optional[Tensor] = None, c=None, text=None, inference_params=None, skip=None):
@@ -460,8 +465,9 @@ class ZigMa(nn.Module):
         residual = None
         if self.fused_add_norm and not (self.training and torch.is_grad_enabled()) and self.use_pe != 3:
             pend = Pending(hidden_states.contiguous())
-            for block in self.blocks:
-                pend, residual = block.forward_fused(pend, residual, c, y)
+            mods, kvs = self._batched_conditioning(c, y)
+            for i, block in enumerate(self.blocks):
+                pend, residual = block.forward_fused(pend, residual, c, y, mod=mods[i], kv=kvs[i] if kvs else None)
             is_rms = isinstance(self.norm_f, RMSNorm)
             _, _, hidden_states, _ = block_norm(pend.base, self.norm_f.weight, self.norm_f.bias, residual,
                                                 self.norm_f.eps, is_rms, residual_in_fp32=self.residual_in_fp32,
@@ -486,6 +492,33 @@ class ZigMa(nn.Module):
         else:
             hidden_states = self.unpatchify(hidden_states)
         return hidden_states.to(in_dtype)
+
+    def _batched_conditioning(self, c, text):
+        """adaLN modulations of ALL blocks in one GEMM, and (has_text) the cross-attention K / V projections of all
+        blocks in one GEMM: they depend on (t, y) only, identically for every block (model_zigma.py:441,447-449 and
+        :104-107 evaluate them block by block: 3 x depth small GEMMs -> 2).  Stacked weights are cached against the
+        parameters' version counters."""
+        blocks = self.blocks
+        plist = [b.adaLN_modulation[-1].weight for b in blocks] + [b.adaLN_modulation[-1].bias for b in blocks]
+        if self.has_text:
+            plist += [b.msa.to_k.weight for b in blocks] + [b.msa.to_v.weight for b in blocks]
+        key = tuple((p._version, p.data_ptr()) for p in plist)
+        cache = getattr(self, "_cond_cache", None)
+        if cache is None or cache[0] != key:
+            Wm = torch.cat([b.adaLN_modulation[-1].weight for b in blocks], 0)
+            bm = torch.cat([b.adaLN_modulation[-1].bias for b in blocks], 0)
+            Wkv = torch.cat([torch.cat([b.msa.to_k.weight, b.msa.to_v.weight], 0) for b in blocks], 0) if self.has_text else None
+            cache = (key, Wm.detach(), bm.detach(), None if Wkv is None else Wkv.detach())
+            self._cond_cache = cache
+        _, Wm, bm, Wkv = cache
+        n = len(blocks)
+        mods = F.linear(F.silu(c), Wm, bm).view(c.shape[0], n, -1).unbind(1)       # n x (B, 3E | 6E), row pitch n*6E
+        kvs = None
+        if self.has_text:
+            inner = blocks[0].msa.to_k.weight.shape[0]
+            kv_all = F.linear(text, Wkv).view(text.shape[0], text.shape[1], n, 2, inner)
+            kvs = [(kv_all[:, :, i, 0], kv_all[:, :, i, 1]) for i in range(n)]
+        return mods, kvs
 
     def forward_with_cfg(self, x, t, y, cfg_scale):
         raise NotImplementedError
