@@ -422,3 +422,28 @@ def test_graphed_forward_matches_eager_and_sampler_runs_on_it():
     assert torch.equal(a, b)
     with pytest.raises(RuntimeError):
         gf(x[:1], t[:1], y[:1])
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("L", [4096, 5000, 8192 + 16])
+def test_scan_tok_sequence_split_vs_oracle(dtype, L):
+    """few samples + long sequence: the kernel splits the sequence over workgroups (pass 1 carries -> combine ->
+    pass 2); result and the carry tensor x must equal the single-pass semantics (oracle)."""
+    from zigma_amd import _lib
+    c = _tok_case(1, L, 64, 16, dtype, True, True, seed=L, real_A=False)
+    y, x = _run_tok(c, dtype, want_x=True)
+    assert _lib.last_kernel().startswith("scan_tok")
+    ref, last = _oracle_tok(c, dtype)
+    if dtype == torch.float32:
+        assert rel_err(N(y), ref) < 2e-5
+    else:
+        assert rel_err(N(y), ref) < 1e-3
+    assert rel_err(N(x[:, :, -1, 1::2]), last) < 2e-5
+    # carries at the 2048 boundaries == state of a scan stopped there
+    c2 = dict(c)
+    for k in ("u", "delta", "xdbl", "zfull"):
+        c2[k] = c[k][:, :2048]
+    c2["perm"] = None
+    c2["has_z"] = False
+    _, last2048 = _oracle_tok(c2, dtype)
+    assert rel_err(N(x[:, :, 0, 1::2]), last2048) < 2e-5

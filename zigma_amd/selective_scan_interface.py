@@ -249,8 +249,12 @@ def mamba_inner_tok(xz, conv1d_weight, conv1d_bias, x_proj_weight, delta_proj_we
     if C_proj_bias is not None:
         Cm = Cm + C_proj_bias.to(Cm.dtype)
     y = out if out is not None else torch.empty(Bsz, L, Di, device=xz.device, dtype=xz.dtype)
+    # long sequences with few samples: hand the kernel a carry buffer so it may split the sequence over workgroups
+    xc = None
+    if L >= 4096 and Bsz * (Di // 64) < 768:
+        xc = torch.empty(Bsz, Di, (L + 2047) // 2048, 2 * N, device=xz.device, dtype=torch.float32)
     scan_raw(u.transpose(1, 2), delta.transpose(1, 2), A, Bm.transpose(1, 2).unsqueeze(1),
              Cm.transpose(1, 2).unsqueeze(1), D, z_half.transpose(1, 2), delta_bias, delta_softplus,
              out_z=y.transpose(1, 2), z_row_index=perm, out_row_index=perm if out_rows is None else out_rows,
-             want_out=False)
+             want_out=False, x=xc)
     return y
