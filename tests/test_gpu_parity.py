@@ -369,6 +369,27 @@ def test_sampler_euler_vs_oracle():
     assert rel_err(N(traj[-1]), ref[-1]) < 2e-4
 
 
+def test_sampler_sde_gpu_matches_oracle_model_on_same_noise():
+    """Sampler.sample_sde on the HIP model vs the same sampler driven by the numpy oracle model, same CPU noise stream
+    (the Wiener increments come from the CPU generator in both runs): Euler-Maruyama + Mean last step, sigma diffusion."""
+    from zigma_amd.transport import ModelType, PathType, Sampler, Transport, WeightType
+    m, g, cfg, y = _load_model("zigma_uncond_zigzag8")
+    state = {k[3:]: v for k, v in g.items() if k.startswith("sd.")}
+    om = zo.ZigMaOracle(state, cfg)
+    tr = Transport(model_type=ModelType.VELOCITY, path_type=PathType.LINEAR, loss_type=WeightType.NONE, train_eps=1e-3,
+                   sample_eps=1e-3)
+    fn = Sampler(tr).sample_sde(sampling_method="Euler", diffusion_form="sigma", diffusion_norm=0.5, num_steps=5)
+    torch.manual_seed(3)
+    z0 = torch.randn(2, 4, 8, 8)
+    torch.manual_seed(4)
+    with torch.no_grad():
+        xs = fn(z0.to(DEV), m.forward)
+    torch.manual_seed(4)
+    ref = fn(z0, lambda x, t: torch.from_numpy(om.forward(x.numpy(), t.numpy())))
+    assert len(xs) == 5 and xs[-1].is_cuda
+    assert rel_err(N(xs[-1]), ref[-1].numpy()) < 5e-4
+
+
 def test_extension_shims_conventions():
     """out inherits delta's strides, x is (B, D, n_chunks, 2N) f32, errors are RuntimeError."""
     from zigma_amd import extension_shims

@@ -152,7 +152,49 @@ def test_transport_rules_and_fixed_grid_solvers():
     rev = Sampler(tr).sample_ode(sampling_method="euler", num_steps=3, reverse=True)(x0, lambda x, t: torch.ones_like(x))
     assert torch.allclose(rev[-1], x0 - 1)                    # reverse integrates from t=1 down to 0
     with pytest.raises(NotImplementedError):
-        Sampler(tr).sample_sde()
+        Sampler(tr).sample_ode_likelihood()
+
+
+def test_sde_sampler_matches_reference_golden():
+    """Sampler.sample_sde (Euler-Maruyama / Heun, every last-step rule, SBDM / sigma / linear / ... diffusions, all three
+    paths and predictions) against trajectories of the unmodified reference on the same CPU RNG stream
+    (oracle/make_golden_sde.py).  The reference evaluates the model twice per drift; one evaluation must give the same."""
+    import ast
+    from zigma_amd.transport import ModelType, PathType, Sampler, Transport, WeightType
+    g = np.load(os.path.join(ROOT, "tests", "golden", "sde_sampler.npz"))
+    cases = ast.literal_eval(str(g["cases"]))
+
+    calls = [0]
+
+    def toy_model(x, t, **kw):
+        calls[0] += 1
+        tt = t.view(-1, *([1] * (x.dim() - 1)))
+        return torch.tanh(x) * (0.3 + tt) - 0.5 * x
+
+    for i, (path, pred, smp, form, norm, last, lss, n) in enumerate(cases):
+        mt = {"velocity": ModelType.VELOCITY, "noise": ModelType.NOISE, "score": ModelType.SCORE}[pred]
+        pt = {"Linear": PathType.LINEAR, "GVP": PathType.GVP, "VP": PathType.VP}[path]
+        tr = Transport(model_type=mt, path_type=pt, loss_type=WeightType.NONE, train_eps=1e-3, sample_eps=1e-3)
+        fn = Sampler(tr).sample_sde(sampling_method=smp, diffusion_form=form, diffusion_norm=norm, last_step=last,
+                                    last_step_size=lss, num_steps=n)
+        torch.manual_seed(100 + i)
+        x0 = torch.randn(3, 2, 4, 4)
+        assert np.array_equal(x0.numpy(), g[f"x0_{i}"])
+        calls[0] = 0
+        xs = fn(x0, toy_model)
+        assert len(xs) == n
+        for key, got in (("last", xs[-1]), ("mid", xs[len(xs) // 2])):
+            ref = g[f"{key}_{i}"]
+            err = np.linalg.norm(got.numpy() - ref) / np.linalg.norm(ref)
+            assert err < 1e-5, (i, key, err)
+        per_step = 1 if smp == "Euler" else 2
+        assert calls[0] == per_step * (n - 1) + (0 if last is None else 1)   # the reference needs twice as many
+    const = Sampler(Transport(model_type=ModelType.VELOCITY, path_type=PathType.LINEAR, loss_type=WeightType.NONE,
+                              train_eps=1e-3, sample_eps=1e-3)).sample_sde(diffusion_form="constant", diffusion_norm=0.1,
+                                                                           num_steps=5)
+    assert torch.isfinite(const(torch.randn(2, 3), toy_model)[-1]).all()    # the reference raises TypeError here
+    with pytest.raises(NotImplementedError):
+        Sampler(tr).sample_sde(sampling_method="nope")(x0, toy_model)
 
 
 def test_plans_match_closed_forms():

@@ -139,10 +139,60 @@ def odeint(func, y0, t, *, method="dopri5", rtol=1e-3, atol=1e-6):
 
 
 class sde:
-    """SDE solver class — outside the round-1 scope."""
+    """SDE solver class (reference transport/integrators.py:9-80): Euler-Maruyama and the stochastic Heun scheme on
+    linspace(t0, t1, num_steps).  The Wiener increments are drawn with th.randn on the CPU generator and moved to the
+    state's device/dtype, exactly like the reference (`th.randn(x.size()).to(x)`), so a seeded run reproduces the
+    reference's noise stream; everything else stays on the device."""
 
-    def __init__(self, *a, **kw):
-        raise NotImplementedError("zigma_amd: SDE sampling is not on the ODE hot path and not built yet")
+    def __init__(self, drift, diffusion, *, t0, t1, num_steps, sampler_type):
+        assert t0 < t1, "SDE sampler has to be in forward time"
+        self.num_timesteps = num_steps
+        self.t = th.linspace(t0, t1, num_steps)
+        self.dt = self.t[1] - self.t[0]
+        self.drift = drift
+        self.diffusion = diffusion
+        self.sampler_type = sampler_type
+
+    @staticmethod
+    def _sqrt2(d, x):
+        # diffusion_form="constant" hands back a Python float (the reference's th.sqrt raises on it)
+        return th.sqrt(2 * (d if th.is_tensor(d) else th.as_tensor(d, dtype=x.dtype, device=x.device)))
+
+    def _euler_maruyama_step(self, x, mean_x, t, model, **model_kwargs):
+        w_cur = th.randn(x.size()).to(x)
+        dt = self.dt.to(x)
+        t = th.ones(x.size(0)).to(x) * t
+        dw = w_cur * th.sqrt(dt)
+        drift = self.drift(x, t, model, **model_kwargs)
+        diffusion = self.diffusion(x, t)
+        mean_x = x + drift * dt
+        x = mean_x + self._sqrt2(diffusion, x) * dw
+        return x, mean_x
+
+    def _heun_step(self, x, _, t, model, **model_kwargs):
+        w_cur = th.randn(x.size()).to(x)
+        dt = self.dt.to(x)
+        dw = w_cur * th.sqrt(dt)
+        t_cur = th.ones(x.size(0)).to(x) * t
+        diffusion = self.diffusion(x, t_cur)
+        xhat = x + self._sqrt2(diffusion, x) * dw
+        K1 = self.drift(xhat, t_cur, model, **model_kwargs)
+        xp = xhat + dt * K1
+        K2 = self.drift(xp, t_cur + dt, model, **model_kwargs)
+        return xhat + 0.5 * dt * (K1 + K2), xhat      # at the last time point no Heun step is performed
+
+    def sample(self, init, model, **model_kwargs):
+        """forward loop of the SDE -> list of num_steps - 1 states"""
+        try:
+            sampler = {"Euler": self._euler_maruyama_step, "Heun": self._heun_step}[self.sampler_type]
+        except KeyError:
+            raise NotImplementedError("Sampler type not implemented.")
+        x, mean_x, samples = init, init, []
+        for ti in self.t[:-1]:
+            with th.no_grad():
+                x, mean_x = sampler(x, mean_x, ti, model, **model_kwargs)
+                samples.append(x)
+        return samples
 
 
 class ode:

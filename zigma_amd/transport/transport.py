@@ -2,14 +2,14 @@
 
 Mirrors the reference's `transport/transport.py`: `ModelType/PathType/WeightType` (:18-40),
 `Transport` (:43-233) and `Sampler` (:236-478).  `Sampler.sample_ode` is the hot path (called by
-sample_acc.py:159-165,362); the SDE and likelihood samplers are later scope rows and raise.
+sample_acc.py:159-165,362); the likelihood sampler is a later scope row and raises.
 """
 import enum
 
 import torch as th
 
 from . import path
-from .integrators import ode
+from .integrators import ode, sde
 from .path import expand_t_like_x
 
 
@@ -136,8 +136,60 @@ class Sampler:
         self.drift = self.transport.get_drift()
         self.score = self.transport.get_score()
 
-    def sample_sde(self, *args, **kwargs):
-        raise NotImplementedError("zigma_amd: sample_sde is a later scope row (SURVEY.md §8f rank 3); use sample_ode")
+    def _sde_drift_and_diffusion(self, *, diffusion_form="SBDM", diffusion_norm=1.0):
+        """drift + w_t * score and w_t (reference transport.py:251-271).  The reference evaluates the network twice per
+        drift call (once inside self.drift, once inside self.score, same arguments); the network is deterministic, so
+        it is evaluated ONCE here and both closures read that output — half the denoiser forwards per SDE step."""
+        ps = self.transport.path_sampler
+
+        def diffusion_fn(x, t):
+            return ps.compute_diffusion(x, t, form=diffusion_form, norm=diffusion_norm)
+
+        def sde_drift(x, t, model, **kw):
+            out = model(x, t, **kw)
+            cached = lambda *_a, **_k: out
+            return self.drift(x, t, cached) + diffusion_fn(x, t) * self.score(x, t, cached)
+
+        return sde_drift, diffusion_fn
+
+    def _last_step(self, sde_drift, *, last_step, last_step_size):
+        """(reference transport.py:273-307)"""
+        if last_step is None:
+            return lambda x, t, model, **kw: x
+        if last_step == "Mean":
+            return lambda x, t, model, **kw: x + sde_drift(x, t, model, **kw) * last_step_size
+        if last_step == "Tweedie":
+            alpha, sigma = self.transport.path_sampler.compute_alpha_t, self.transport.path_sampler.compute_sigma_t
+            return lambda x, t, model, **kw: (x / alpha(t)[0][0]
+                                              + (sigma(t)[0][0] ** 2) / alpha(t)[0][0] * self.score(x, t, model, **kw))
+        if last_step == "Euler":
+            return lambda x, t, model, **kw: x + self.drift(x, t, model, **kw) * last_step_size
+        raise NotImplementedError()
+
+    def sample_sde(self, *, sampling_method="Euler", diffusion_form="SBDM", diffusion_norm=1.0, last_step="Mean",
+                   last_step_size=0.04, num_steps=250):
+        """returns fn(init_z, model, **model_kwargs) -> list of num_steps states (reference transport.py:309-370):
+        num_steps - 1 solver steps on linspace(t0, t1, num_steps) plus the last step ("Mean" | "Tweedie" | "Euler" | None)
+        from t1 = 1 - last_step_size."""
+        if last_step is None:
+            last_step_size = 0.0
+        sde_drift, sde_diffusion = self._sde_drift_and_diffusion(diffusion_form=diffusion_form,
+                                                                  diffusion_norm=diffusion_norm)
+        t0, t1 = self.transport.check_interval(self.transport.train_eps, self.transport.sample_eps,
+                                               diffusion_form=diffusion_form, sde=True, eval=True, reverse=False,
+                                               last_step_size=last_step_size)
+        _sde = sde(sde_drift, sde_diffusion, t0=t0, t1=t1, num_steps=num_steps, sampler_type=sampling_method)
+        last_step_fn = self._last_step(sde_drift, last_step=last_step, last_step_size=last_step_size)
+
+        def _sample(init_z, model, **model_kwargs):
+            xs = _sde.sample(init_z, model, **model_kwargs)
+            ts = th.ones(init_z.size(0), device=init_z.device) * t1
+            with th.no_grad():
+                xs.append(last_step_fn(xs[-1], ts, model, **model_kwargs))
+            assert len(xs) == num_steps, "Samples does not match the number of steps"
+            return xs
+
+        return _sample
 
     def sample_ode(self, *, sampling_method="dopri5", num_steps=50, atol=1e-6, rtol=1e-3, reverse=False):
         """returns fn(x, model, **model_kwargs) -> Tensor(num_steps, *x.shape); callers take [-1].
