@@ -176,3 +176,17 @@ def reference_modules():
             importlib.import_module("dis_mamba.mamba_ssm.ops.selective_scan_interface"),
             importlib.import_module("causal_conv1d.causal_conv1d_interface"),
             importlib.import_module("utils.utils_zigzag"))
+
+
+def reference_layernorm():
+    """The reference's own pure-torch `layer_norm_ref` / `rms_norm_ref` (layernorm.py:18-46), taken from its source
+    file WITHOUT importing the module (its top level needs triton): the two function definitions are compiled as they
+    stand into a namespace that only holds torch and torch.nn.functional."""
+    import ast
+    path = REF + "/dis_mamba/mamba_ssm/ops/triton/layernorm.py"
+    tree = ast.parse(open(path).read(), filename=path)
+    keep = [n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name in ("layer_norm_ref", "rms_norm_ref")]
+    assert len(keep) == 2
+    ns = {"torch": torch, "F": F}
+    exec(compile(ast.Module(body=keep, type_ignores=[]), path, "exec"), ns)
+    return types.SimpleNamespace(layer_norm_ref=ns["layer_norm_ref"], rms_norm_ref=ns["rms_norm_ref"])

@@ -492,3 +492,146 @@ def sample_ode_fixed(model_fn, x0, num_steps=50, method="euler", t0=0.0, t1=1.0,
             raise ValueError(method)
         traj.append(x)
     return np.stack(traj)
+
+
+# ---------------------------------------------------------------------------------------------------
+# Backward restatements.  Same role as the forward ones: checker for the HIP
+# backward kernels; pinned against autograd through the reference's pure-torch forward
+# (oracle/make_golden_bwd.py -> tests/golden/bwd_*.npz).
+# ---------------------------------------------------------------------------------------------------
+def selective_scan_bwd(u, delta, A, B, C, D, z, delta_bias, dout, delta_softplus=False, dt=np.float64):
+    """Gradients of `selective_scan` (real A, variable B/C of shape (B, N, L) / (B, 1, N, L), or constant (D, N)).
+
+    Math of selective_scan_bwd_kernel.cuh:161-329 (what the reference's CUDA backward computes; its python
+    reference gets the same numbers from autograd, test_selective_scan.py:100-149):
+      g = dout * silu(z);  dz = dout * y * sigmoid(z) * (1 + z * (1 - sigmoid(z)))
+      dh_l = g_l C_l + a_{l+1} dh_{l+1};  dC_l = sum_d g_l h_l;  dB_l = sum_d dh_l * delta_l * u_l
+      du_l = g_l D + delta_l * sum_n dh_l B_l;  ddelta_l = sum_n dh_l (B_l u_l + A a_l h_{l-1})
+      dA = sum_{b,l} dh_l * delta_l * a_l * h_{l-1};  dD = sum g u;  softplus' = sigmoid(delta_raw) (delta_raw <= 20)
+    Returns dict(du, ddelta, dA, dB, dC, dD, dz, ddelta_bias) — entries None where the input was None."""
+    u = np.asarray(u, dtype=dt)
+    draw = np.asarray(delta, dtype=dt)
+    A = np.asarray(A, dtype=dt)
+    dout = np.asarray(dout, dtype=dt)
+    Bsz, Dm, L = u.shape
+    N = A.shape[1]
+    if delta_bias is not None:
+        draw = draw + np.asarray(delta_bias, dtype=dt)[None, :, None]
+    dl_all = softplus(draw) if delta_softplus else draw
+    Bv = np.asarray(B, dtype=dt)
+    Cv = np.asarray(C, dtype=dt)
+    var_B, var_C = Bv.ndim >= 3, Cv.ndim >= 3
+    if Bv.ndim == 4:
+        assert Bv.shape[1] == 1, "oracle backward: one B/C group"
+        Bv = Bv[:, 0]
+    if Cv.ndim == 4:
+        Cv = Cv[:, 0]
+    # forward, keeping every state
+    H = np.zeros((L + 1, Bsz, Dm, N), dtype=dt)
+    a_all = np.empty((L, Bsz, Dm, N), dtype=dt)
+    y = np.empty((Bsz, Dm, L), dtype=dt)
+    for l in range(L):
+        dl = dl_all[:, :, l, None]
+        a_all[l] = np.exp(dl * A[None])
+        bl = Bv[:, None, :, l] if var_B else Bv[None]
+        H[l + 1] = a_all[l] * H[l] + dl * u[:, :, l, None] * bl
+        cl = Cv[:, None, :, l] if var_C else Cv[None]
+        y[:, :, l] = (H[l + 1] * cl).sum(-1)
+    if D is not None:
+        y = y + u * np.asarray(D, dtype=dt)[None, :, None]
+    if z is not None:
+        zf = np.asarray(z, dtype=dt)
+        sg = sigmoid(zf)
+        g = dout * zf * sg
+        dz = dout * y * sg * (1.0 + zf * (1.0 - sg))
+    else:
+        g, dz = dout, None
+    du = np.zeros_like(u)
+    ddl = np.zeros_like(u)
+    dA = np.zeros((Dm, N), dtype=dt)
+    dB = np.zeros_like(Bv)
+    dC = np.zeros_like(Cv)
+    adh = np.zeros((Bsz, Dm, N), dtype=dt)
+    for l in range(L - 1, -1, -1):
+        dl = dl_all[:, :, l, None]
+        bl = Bv[:, None, :, l] if var_B else Bv[None]
+        cl = Cv[:, None, :, l] if var_C else Cv[None]
+        dh = g[:, :, l, None] * cl + adh
+        ahm = a_all[l] * H[l]                                   # a_l h_{l-1}
+        if var_C:
+            dC[:, :, l] = (g[:, :, l, None] * H[l + 1]).sum(1)
+        else:
+            dC += (g[:, :, l, None] * H[l + 1]).sum(0)
+        if var_B:
+            dB[:, :, l] = (dh * dl * u[:, :, l, None]).sum(1)
+        else:
+            dB += (dh * dl * u[:, :, l, None]).sum(0)
+        sp = (dh * bl).sum(-1)
+        du[:, :, l] = dl[:, :, 0] * sp
+        ddl[:, :, l] = u[:, :, l] * sp + (dh * A[None] * ahm).sum(-1)
+        dA += (dh * dl * ahm).sum(0)
+        adh = a_all[l] * dh
+    dD = None
+    if D is not None:
+        du = du + g * np.asarray(D, dtype=dt)[None, :, None]
+        dD = (g * u).sum((0, 2))
+    if delta_softplus:
+        ddl = ddl * np.where(draw <= 20.0, sigmoid(draw), 1.0)
+    dbias = ddl.sum((0, 2)) if delta_bias is not None else None
+    return dict(du=du, ddelta=ddl, dA=dA, dB=dB, dC=dC, dD=dD, dz=dz, ddelta_bias=dbias)
+
+
+def causal_conv1d_bwd(x, weight, bias, dout, activation=None, dt=np.float64):
+    """Gradients of `causal_conv1d` (causal_conv1d_bwd.cu:46-240): x, dout (B, D, L); weight (D, W).
+    Returns (dx, dweight, dbias)."""
+    x = np.asarray(x, dtype=dt)
+    w = np.asarray(weight, dtype=dt)
+    dout = np.asarray(dout, dtype=dt)
+    _, Dm, L = x.shape
+    W = w.shape[1]
+    if activation in ("silu", "swish"):
+        pre = causal_conv1d(x, w, bias, None, dt=dt)
+        sg = sigmoid(pre)
+        dout = dout * sg * (1.0 + pre * (1.0 - sg))
+    dx = np.zeros_like(x)
+    dw = np.zeros_like(w)
+    for k in range(W):
+        shift = W - 1 - k
+        if shift >= L:
+            continue
+        dx[:, :, :L - shift] += w[None, :, k, None] * dout[:, :, shift:]
+        dw[:, k] = (dout[:, :, shift:] * x[:, :, :L - shift]).sum((0, 2))
+    db = dout.sum((0, 2)) if bias is not None else None
+    return dx, dw, db
+
+
+def fused_add_norm_bwd(x, weight, bias, residual, dy, dresidual_out=None, eps=1e-6, rms=True, dt=np.float64):
+    """Gradients of `fused_add_norm` (layernorm.py:196-377): returns (dx, dweight, dbias, dresidual).
+    dresidual_out is the gradient flowing into the second output of the prenorm form.  x and residual enter
+    through their sum, so dx == dresidual (the reference returns the same tensor for both when dtypes match)."""
+    xf = np.asarray(x, dtype=dt)
+    if residual is not None:
+        xf = xf + np.asarray(residual, dtype=dt)
+    dy = np.asarray(dy, dtype=dt)
+    Ncol = xf.shape[-1]
+    w = np.ones(Ncol, dtype=dt) if weight is None else np.asarray(weight, dtype=dt)
+    if rms:
+        rstd = 1.0 / np.sqrt((xf * xf).mean(-1, keepdims=True) + eps)
+        xhat = xf * rstd
+    else:
+        mu = xf.mean(-1, keepdims=True)
+        rstd = 1.0 / np.sqrt(((xf - mu) ** 2).mean(-1, keepdims=True) + eps)
+        xhat = (xf - mu) * rstd
+    wdy = dy * w
+    c1 = (xhat * wdy).mean(-1, keepdims=True)
+    if rms:
+        dxs = (wdy - xhat * c1) * rstd
+    else:
+        c2 = wdy.mean(-1, keepdims=True)
+        dxs = (wdy - (xhat * c1 + c2)) * rstd
+    if dresidual_out is not None:
+        dxs = dxs + np.asarray(dresidual_out, dtype=dt)
+    lead = tuple(range(dy.ndim - 1))
+    dw = (dy * xhat).sum(lead) if weight is not None else None
+    db = dy.sum(lead) if bias is not None else None
+    return dxs, dw, db, (dxs if residual is not None else None)
