@@ -187,6 +187,60 @@ typedef struct zigma_dtproj_params {
 
 int zigma_dt_proj_softplus_fwd(const zigma_dtproj_params_t *p, void *stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Selective scan backward (token-major operands, real A, variable B/C, one group).
+ * Replaces  selective_scan_cuda.bwd  (reference dis_mamba/csrc/selective_scan/selective_scan.cpp:338-492, kernel
+ * selective_scan_bwd_kernel.cuh:59-329, reverse_scan.cuh) for the layout the fused block uses.  Given dout = dL/d(out_z)
+ * (or dL/d(out) when z == NULL) it produces (selective_scan_bwd_kernel.cuh:161-329):
+ *   g = dout * silu(z);  dz = dout * out * sigmoid(z) * (1 + z (1 - sigmoid(z)))          (out = the forward's UNGATED y)
+ *   dh_l = g_l C_l + a_{l+1} dh_{l+1};   dC[b,n,l] = sum_d g_l h_l;   dB[b,n,l] = sum_d dh_l delta'_l u_l
+ *   du = g D + delta' sum_n dh B;   ddelta = (sum_n dh (B u + A a h_{l-1})) * softplus'(delta + bias)
+ *   dA[d,n] = sum_{b,l} dh delta' a h_{l-1};   dD[d] = sum g u;   ddelta_bias[d] = sum ddelta
+ * u, delta, z, out, dout, du, ddelta, dz: (batch, seqlen, dim), channel stride 1, io_dtype; B, C: (batch, dstate, seqlen)
+ * logical with arbitrary strides, io_dtype; dB, dC: float32, same logical shape, arbitrary strides (e.g. columns of a
+ * float32 d(x_dbl) buffer); dA (dim, dstate), dD (dim), ddelta_bias (dim): float32 contiguous, WRITTEN (not accumulated).
+ * The reverse sweep re-creates the states from checkpoints every 16 steps, which the kernel writes itself in a first
+ * forward phase: the caller provides `workspace` of zigma_selective_scan_bwd_workspace_bytes() bytes (the library
+ * never allocates).  All sums are formed in a fixed order: results are bit-reproducible run to run.
+ * Limits: dim % 64 == 0, dstate 16 or 8.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct zigma_scan_bwd_params {
+    int32_t batch, dim, seqlen, dstate;
+    int32_t delta_softplus;
+    int32_t io_dtype;
+    int32_t flags;           /* reserved, must be 0 */
+    int32_t pad_;
+    int64_t u_batch_stride, u_l_stride;
+    int64_t delta_batch_stride, delta_l_stride;
+    int64_t z_batch_stride, z_l_stride;
+    int64_t out_batch_stride, out_l_stride;
+    int64_t dout_batch_stride, dout_l_stride;
+    int64_t du_batch_stride, du_l_stride;
+    int64_t ddelta_batch_stride, ddelta_l_stride;
+    int64_t dz_batch_stride, dz_l_stride;
+    int64_t A_d_stride, A_dstate_stride;
+    int64_t B_batch_stride, B_dstate_stride, B_l_stride;
+    int64_t C_batch_stride, C_dstate_stride, C_l_stride;
+    int64_t dB_batch_stride, dB_dstate_stride, dB_l_stride;
+    int64_t dC_batch_stride, dC_dstate_stride, dC_l_stride;
+    const void *u, *delta, *A, *B, *C;
+    const void *D;           /* float32 (dim) or NULL */
+    const void *delta_bias;  /* float32 (dim) or NULL */
+    const void *z;           /* or NULL */
+    const void *out;         /* ungated forward output; required iff z != NULL */
+    const void *dout;
+    void *du, *ddelta;
+    void *dz;                /* required iff z != NULL */
+    float *dA, *dB, *dC;
+    float *dD;               /* required iff D != NULL */
+    float *ddelta_bias;      /* required iff delta_bias != NULL */
+    void *workspace;
+    int64_t workspace_bytes;
+} zigma_scan_bwd_params_t;
+
+int64_t zigma_selective_scan_bwd_workspace_bytes(const zigma_scan_bwd_params_t *p);
+int zigma_selective_scan_bwd(const zigma_scan_bwd_params_t *p, void *stream);
+
 /* ------------------------------------------------------------------------------------------ */
 const char *zigma_strerror(int status);
 int zigma_abi_version(void);

@@ -42,7 +42,8 @@ def test_ctypes_structs_match_the_header():
     """sizeof/offsetof of every field, as gcc sees include/zigma_hip.h, equal the ctypes mirror."""
     from zigma_amd import _lib
     structs = {"zigma_scan_params_t": _lib.ScanParams, "zigma_conv_params_t": _lib.ConvParams,
-               "zigma_norm_params_t": _lib.NormParams, "zigma_dtproj_params_t": _lib.DtProjParams}
+               "zigma_norm_params_t": _lib.NormParams, "zigma_dtproj_params_t": _lib.DtProjParams,
+               "zigma_scan_bwd_params_t": _lib.ScanBwdParams}
     lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "zigma_hip.h"', "int main(void){"]
     for cname, st in structs.items():
         lines.append(f'printf("{cname} %zu\\n", sizeof({cname}));')

@@ -64,7 +64,22 @@ class DtProjParams(C.Structure):
                 + [(n, vp) for n in ("x", "w", "bias", "out")])
 
 
-EXPORTS = ("zigma_selective_scan_fwd", "zigma_causal_conv1d_fwd", "zigma_add_norm_fwd", "zigma_dt_proj_softplus_fwd", "zigma_strerror",
+class ScanBwdParams(C.Structure):
+    _fields_ = ([(n, i32) for n in ("batch", "dim", "seqlen", "dstate", "delta_softplus", "io_dtype", "flags", "pad_")]
+                + [(n, i64) for n in (
+                    "u_batch_stride", "u_l_stride", "delta_batch_stride", "delta_l_stride", "z_batch_stride", "z_l_stride",
+                    "out_batch_stride", "out_l_stride", "dout_batch_stride", "dout_l_stride", "du_batch_stride",
+                    "du_l_stride", "ddelta_batch_stride", "ddelta_l_stride", "dz_batch_stride", "dz_l_stride",
+                    "A_d_stride", "A_dstate_stride", "B_batch_stride", "B_dstate_stride", "B_l_stride",
+                    "C_batch_stride", "C_dstate_stride", "C_l_stride", "dB_batch_stride", "dB_dstate_stride",
+                    "dB_l_stride", "dC_batch_stride", "dC_dstate_stride", "dC_l_stride")]
+                + [(n, vp) for n in ("u", "delta", "A", "B", "C", "D", "delta_bias", "z", "out", "dout", "du", "ddelta",
+                                     "dz", "dA", "dB", "dC", "dD", "ddelta_bias", "workspace")]
+                + [("workspace_bytes", i64)])
+
+
+EXPORTS = ("zigma_selective_scan_fwd", "zigma_causal_conv1d_fwd", "zigma_add_norm_fwd", "zigma_dt_proj_softplus_fwd", "zigma_selective_scan_bwd",
+           "zigma_selective_scan_bwd_workspace_bytes", "zigma_strerror",
            "zigma_abi_version", "zigma_last_kernel")
 
 _lib = None
@@ -80,10 +95,13 @@ def lib():
                 "There is no CPU or eager fallback for the HIP ops.")
         L = C.CDLL(LIB_PATH)
         for name, st in (("zigma_selective_scan_fwd", ScanParams), ("zigma_causal_conv1d_fwd", ConvParams),
-                         ("zigma_add_norm_fwd", NormParams), ("zigma_dt_proj_softplus_fwd", DtProjParams)):
+                         ("zigma_add_norm_fwd", NormParams), ("zigma_dt_proj_softplus_fwd", DtProjParams),
+                         ("zigma_selective_scan_bwd", ScanBwdParams)):
             fn = getattr(L, name)
             fn.argtypes = [C.POINTER(st), vp]
             fn.restype = C.c_int
+        L.zigma_selective_scan_bwd_workspace_bytes.argtypes = [C.POINTER(ScanBwdParams)]
+        L.zigma_selective_scan_bwd_workspace_bytes.restype = C.c_int64
         L.zigma_strerror.argtypes = [C.c_int]
         L.zigma_strerror.restype = C.c_char_p
         L.zigma_abi_version.restype = C.c_int

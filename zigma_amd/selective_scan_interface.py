@@ -162,6 +162,61 @@ def dt_proj_softplus(x_dbl, dt_rank, weight, bias=None, softplus=True):
     return out.reshape(*lead, n)
 
 
+def scan_bwd_tok(u, delta, A, B, C, D, z, delta_bias, dout, out, delta_softplus, *, dB=None, dC=None):
+    """Backward of the token-major selective scan (zigma_selective_scan_bwd; reference selective_scan_cuda.bwd,
+    selective_scan.cpp:338-492).
+
+    u, delta, z, out, dout: (batch, seqlen, dim), channel stride 1; out = the forward's UNGATED y (only with z).
+    B, C: (batch, seqlen, dstate)-shaped views (any strides), same dtype.  A (dim, dstate) f32, D / delta_bias f32.
+    dB, dC: optional preallocated float32 (batch, seqlen, dstate) views to write into (e.g. columns of d(x_dbl)).
+    Returns du, ddelta, dA, dB, dC, dD, dz, ddelta_bias (None where the input was None); du/ddelta/dz in the input dtype,
+    the rest float32."""
+    dev = _lib.require_device(u, delta, A, B, C, D, z, delta_bias, dout, out)
+    Bsz, L, Dm = u.shape
+    N = A.shape[1]
+    for t, nm in ((u, "u"), (delta, "delta"), (z, "z"), (out, "out"), (dout, "dout")):
+        if t is not None and (t.shape != (Bsz, L, Dm) or t.stride(2) != 1 or t.dtype != u.dtype):
+            raise RuntimeError(f"{nm} must be (batch, seqlen, dim) with channel stride 1 and the dtype of u")
+    if B.shape != (Bsz, L, N) or C.shape != (Bsz, L, N) or B.dtype != u.dtype or C.dtype != u.dtype:
+        raise RuntimeError("B, C must be (batch, seqlen, dstate) views in the dtype of u")
+    if A.dtype != torch.float32:
+        raise RuntimeError("A must be float32")
+    if z is not None and out is None:
+        raise RuntimeError("the gated backward needs the forward's ungated `out`")
+    du, ddelta = torch.empty_like(u, memory_format=torch.contiguous_format), torch.empty_like(u, memory_format=torch.contiguous_format)
+    dz = torch.empty_like(u, memory_format=torch.contiguous_format) if z is not None else None
+    f32 = dict(device=u.device, dtype=torch.float32)
+    dA = torch.zeros(Dm, N, **f32)
+    dB = torch.empty(Bsz, L, N, **f32) if dB is None else dB
+    dC = torch.empty(Bsz, L, N, **f32) if dC is None else dC
+    dD = torch.zeros(Dm, **f32) if D is not None else None
+    dbias = torch.zeros(Dm, **f32) if delta_bias is not None else None
+    P = _lib.ScanBwdParams()
+    P.batch, P.dim, P.seqlen, P.dstate = Bsz, Dm, L, N
+    P.delta_softplus, P.io_dtype, P.flags = int(bool(delta_softplus)), _lib.dtype_id(u), 0
+    for name, t in (("u", u), ("delta", delta), ("z", z), ("out", out), ("dout", dout), ("du", du), ("ddelta", ddelta),
+                    ("dz", dz)):
+        if t is not None:
+            setattr(P, name, _lib.ptr(t))
+            setattr(P, name + "_batch_stride", t.stride(0))
+            setattr(P, name + "_l_stride", t.stride(1))
+    P.A, P.A_d_stride, P.A_dstate_stride = _lib.ptr(A), A.stride(0), A.stride(1)
+    for name, t in (("B", B), ("C", C), ("dB", dB), ("dC", dC)):
+        setattr(P, name, _lib.ptr(t))
+        setattr(P, name + "_batch_stride", t.stride(0))
+        setattr(P, name + "_l_stride", t.stride(1))
+        setattr(P, name + "_dstate_stride", t.stride(2))
+    for t, nm in ((D, "D"), (delta_bias, "delta_bias")):
+        if t is not None and (t.dtype != torch.float32 or not t.is_contiguous()):
+            raise RuntimeError(f"{nm} must be contiguous float32")
+    P.D, P.delta_bias, P.dA, P.dD, P.ddelta_bias = _lib.ptr(D), _lib.ptr(delta_bias), _lib.ptr(dA), _lib.ptr(dD), _lib.ptr(dbias)
+    nbytes = _lib.lib().zigma_selective_scan_bwd_workspace_bytes(P)
+    ws = torch.empty(max(nbytes, 16), device=u.device, dtype=torch.uint8)
+    P.workspace, P.workspace_bytes = _lib.ptr(ws), nbytes
+    _lib.call("zigma_selective_scan_bwd", P, dev)
+    return du, ddelta, dA, dB, dC, dD, dz, dbias
+
+
 def selective_scan_cuda_fwd(u, delta, A, B, C, D_, z_, delta_bias_, delta_softplus):
     """Drop-in for the extension entry `selective_scan_cuda.fwd` -> [out, x] (+ [out_z] if z).
     Callee allocates: out = empty_like(delta), x (B, D, ceil(L/2048), 2N) f32, out_z = empty_like(z)."""
