@@ -241,6 +241,70 @@ typedef struct zigma_scan_bwd_params {
 int64_t zigma_selective_scan_bwd_workspace_bytes(const zigma_scan_bwd_params_t *p);
 int zigma_selective_scan_bwd(const zigma_scan_bwd_params_t *p, void *stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Depthwise causal conv1d (+ bias, + SiLU) backward, token-major operands.
+ * Replaces  causal_conv1d_cuda.causal_conv1d_bwd  (reference dis_causal_conv1d/csrc/causal_conv1d.cpp:191-283,
+ * kernels causal_conv1d_bwd.cu:46-240,301-470).  x, dout, dx: (batch, seqlen, dim), channel stride 1, io_dtype;
+ * dout is in SCAN order (the order the forward wrote `out` in); x is read through x_row_index exactly as in the
+ * forward and dx is scattered through the same table (dx[row[k]] = dx'[k]; the table must be a permutation).
+ * dweight (dim, width), dbias (dim): float32 contiguous, WRITTEN.  Sums are formed in a fixed order.
+ * workspace: zigma_causal_conv1d_bwd_workspace_bytes() bytes.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct zigma_conv_bwd_params {
+    int32_t batch, dim, seqlen, width;
+    int32_t silu_activation;
+    int32_t io_dtype;  /* x, dout, dx */
+    int32_t w_dtype;   /* weight, bias */
+    int32_t flags;     /* reserved, must be 0 */
+    int64_t x_batch_stride, x_l_stride;
+    int64_t dout_batch_stride, dout_l_stride;
+    int64_t dx_batch_stride, dx_l_stride;
+    int64_t weight_c_stride, weight_width_stride;
+    const void *x, *weight;
+    const void *bias;  /* or NULL */
+    const void *dout;
+    void *dx;
+    float *dweight;
+    float *dbias;      /* required iff bias != NULL */
+    const int32_t *x_row_index;
+    void *workspace;
+    int64_t workspace_bytes;
+} zigma_conv_bwd_params_t;
+
+int64_t zigma_causal_conv1d_bwd_workspace_bytes(const zigma_conv_bwd_params_t *p);
+int zigma_causal_conv1d_bwd(const zigma_conv_bwd_params_t *p, void *stream);
+
+/* ------------------------------------------------------------------------------------------
+ * RMSNorm / LayerNorm (+ residual add, prenorm) backward.
+ * Replaces `_layer_norm_bwd` + `_layer_norm_bwd_kernel` (reference dis_mamba/mamba_ssm/ops/triton/layernorm.py:196-377).
+ * xsum = the tensor that was normalised in the forward (x, or the forward's residual_out = x + residual), res_dtype;
+ * mean / rstd are recomputed from it.  dy: gradient of the normalised output (x_dtype); dresidual_out (optional,
+ * res_dtype): gradient arriving at the prenorm residual output.  Writes dx (x_dtype) and / or dresidual (res_dtype)
+ * — both carry  (wdy - xhat*mean(xhat*wdy) - mean(wdy)) * rstd + dresidual_out  — and dweight / dbias (float32 (cols),
+ * WRITTEN, fixed summation order).  workspace: zigma_add_norm_bwd_workspace_bytes() bytes.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct zigma_norm_bwd_params {
+    int32_t rows, cols;
+    int32_t is_rms;
+    int32_t x_dtype, res_dtype, w_dtype;
+    float eps;
+    int32_t flags;           /* reserved, must be 0 */
+    int64_t xsum_row_stride, dy_row_stride, dres_out_row_stride, dx_row_stride, dres_row_stride;
+    const void *xsum;
+    const void *weight;      /* or NULL */
+    const void *dy;
+    const void *dresidual_out;  /* or NULL */
+    void *dx;                /* or NULL */
+    void *dresidual;         /* or NULL (at least one of dx / dresidual) */
+    float *dweight;          /* or NULL */
+    float *dbias;            /* or NULL */
+    void *workspace;
+    int64_t workspace_bytes;
+} zigma_norm_bwd_params_t;
+
+int64_t zigma_add_norm_bwd_workspace_bytes(const zigma_norm_bwd_params_t *p);
+int zigma_add_norm_bwd(const zigma_norm_bwd_params_t *p, void *stream);
+
 /* ------------------------------------------------------------------------------------------ */
 const char *zigma_strerror(int status);
 int zigma_abi_version(void);

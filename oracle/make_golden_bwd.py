@@ -102,5 +102,38 @@ def main():
     save("bwd_mamba_inner.npz", dout=dout, out=out, **leaves, **{"d_" + k: v.grad for k, v in leaves.items()})
 
 
+def model_grads():
+    """Parameter / input gradients of the whole (small) reference model: the reference's Mamba calls `mamba_inner_fn`
+    (an autograd Function over its CUDA forward/backward); here that name is bound to the reference's own pure-torch
+    `mamba_inner_ref` with pure-torch conv / scan inside, so the gradients are autograd's."""
+    import ast
+    with contextlib.redirect_stdout(io.StringIO()):
+        mz, ssi, cci, uz = ref_shim.reference_modules()
+    import dis_mamba.mamba_ssm.modules.mamba_simple as ms
+    ssi.selective_scan_fn = ssi.selective_scan_ref
+    ssi.causal_conv1d_fn = lambda x, w, b, act: cci.causal_conv1d_ref(x, w, b, activation=act)
+    ms.mamba_inner_fn = ssi.mamba_inner_ref
+    for name in ("zigma_text_zigzag2", "zigma_uncond_zigzag8"):
+        g = np.load(os.path.join(OUT, name + ".npz"))
+        cfg = ast.literal_eval(str(g["cfg"]))
+        with contextlib.redirect_stdout(io.StringIO()):
+            m = mz.ZigMa(device="cpu", **cfg).eval()
+        m.load_state_dict({k[3:]: torch.from_numpy(g[k]) for k in g.files if k.startswith("sd.")})
+        x = torch.from_numpy(g["x"]).requires_grad_(True)
+        t = torch.from_numpy(g["t"])
+        y = torch.from_numpy(g["y"]) if "y" in g.files else None
+        out = m(x, t, y)
+        assert np.allclose(out.detach().numpy(), g["out"], rtol=1e-4, atol=1e-5), "differentiable path != fixture forward"
+        wgt = torch.randn(out.shape, generator=torch.Generator().manual_seed(77))
+        (out * wgt).sum().backward()
+        arrs = {"g." + k: p.grad for k, p in m.named_parameters() if p.grad is not None}
+        arrs["gx"] = x.grad
+        arrs["wgt"] = wgt
+        save("bwd_model_" + name + ".npz", **arrs)
+
+
 if __name__ == "__main__":
-    main()
+    import sys
+    if "--model-only" not in sys.argv:
+        main()
+    model_grads()

@@ -78,8 +78,28 @@ class ScanBwdParams(C.Structure):
                 + [("workspace_bytes", i64)])
 
 
+class ConvBwdParams(C.Structure):
+    _fields_ = ([(n, i32) for n in ("batch", "dim", "seqlen", "width", "silu_activation", "io_dtype", "w_dtype", "flags")]
+                + [(n, i64) for n in ("x_batch_stride", "x_l_stride", "dout_batch_stride", "dout_l_stride", "dx_batch_stride",
+                                      "dx_l_stride", "weight_c_stride", "weight_width_stride")]
+                + [(n, vp) for n in ("x", "weight", "bias", "dout", "dx", "dweight", "dbias", "x_row_index", "workspace")]
+                + [("workspace_bytes", i64)])
+
+
+class NormBwdParams(C.Structure):
+    _fields_ = ([(n, i32) for n in ("rows", "cols", "is_rms", "x_dtype", "res_dtype", "w_dtype")]
+                + [("eps", f32), ("flags", i32)]
+                + [(n, i64) for n in ("xsum_row_stride", "dy_row_stride", "dres_out_row_stride", "dx_row_stride",
+                                      "dres_row_stride")]
+                + [(n, vp) for n in ("xsum", "weight", "dy", "dresidual_out", "dx", "dresidual", "dweight", "dbias",
+                                     "workspace")]
+                + [("workspace_bytes", i64)])
+
+
 EXPORTS = ("zigma_selective_scan_fwd", "zigma_causal_conv1d_fwd", "zigma_add_norm_fwd", "zigma_dt_proj_softplus_fwd", "zigma_selective_scan_bwd",
-           "zigma_selective_scan_bwd_workspace_bytes", "zigma_strerror",
+           "zigma_selective_scan_bwd_workspace_bytes", "zigma_causal_conv1d_bwd",
+           "zigma_causal_conv1d_bwd_workspace_bytes", "zigma_add_norm_bwd", "zigma_add_norm_bwd_workspace_bytes",
+           "zigma_strerror",
            "zigma_abi_version", "zigma_last_kernel")
 
 _lib = None
@@ -96,12 +116,17 @@ def lib():
         L = C.CDLL(LIB_PATH)
         for name, st in (("zigma_selective_scan_fwd", ScanParams), ("zigma_causal_conv1d_fwd", ConvParams),
                          ("zigma_add_norm_fwd", NormParams), ("zigma_dt_proj_softplus_fwd", DtProjParams),
-                         ("zigma_selective_scan_bwd", ScanBwdParams)):
+                         ("zigma_selective_scan_bwd", ScanBwdParams), ("zigma_causal_conv1d_bwd", ConvBwdParams),
+                         ("zigma_add_norm_bwd", NormBwdParams)):
             fn = getattr(L, name)
             fn.argtypes = [C.POINTER(st), vp]
             fn.restype = C.c_int
-        L.zigma_selective_scan_bwd_workspace_bytes.argtypes = [C.POINTER(ScanBwdParams)]
-        L.zigma_selective_scan_bwd_workspace_bytes.restype = C.c_int64
+        for name, st in (("zigma_selective_scan_bwd_workspace_bytes", ScanBwdParams),
+                         ("zigma_causal_conv1d_bwd_workspace_bytes", ConvBwdParams),
+                         ("zigma_add_norm_bwd_workspace_bytes", NormBwdParams)):
+            fn = getattr(L, name)
+            fn.argtypes = [C.POINTER(st)]
+            fn.restype = C.c_int64
         L.zigma_strerror.argtypes = [C.c_int]
         L.zigma_strerror.restype = C.c_char_p
         L.zigma_abi_version.restype = C.c_int
@@ -140,6 +165,14 @@ def require_device(*tensors):
         elif t.device != dev:
             raise RuntimeError("zigma_amd: all tensors must be on the same device")
     return dev
+
+
+def workspace(fn_name, params, device):
+    """Allocate the caller-owned scratch buffer a backward entry point asks for and attach it to the parameter block."""
+    nbytes = getattr(lib(), fn_name + "_workspace_bytes")(C.byref(params))
+    ws = torch.empty(max(int(nbytes), 16), device=device, dtype=torch.uint8)
+    params.workspace, params.workspace_bytes = ws.data_ptr(), nbytes
+    return ws
 
 
 def call(fn_name, params, device):

@@ -56,3 +56,37 @@ def causal_conv1d_fn(x, weight, bias=None, activation=None):
     if activation not in [None, "silu", "swish"]:
         raise NotImplementedError("activation must be None, silu, or swish")
     return causal_conv1d_raw(x, weight, bias, activation in ["silu", "swish"])
+
+
+def conv_bwd_tok(x, weight, bias, dout, silu, x_row_index=None):
+    """Backward of the token-major causal conv (zigma_causal_conv1d_bwd; reference causal_conv1d_cuda.causal_conv1d_bwd,
+    causal_conv1d.cpp:191-283).  x, dout: (batch, seqlen, dim), channel stride 1; dout in SCAN order; x is read through
+    x_row_index as in the forward and dx is scattered back through it.  Returns dx (dtype of x), dweight (dim, width) f32,
+    dbias (dim) f32 or None."""
+    dev = _lib.require_device(x, weight, bias, dout, x_row_index)
+    Bsz, L, Dm = x.shape
+    if dout.shape != x.shape or x.stride(2) != 1 or dout.stride(2) != 1 or dout.dtype != x.dtype:
+        raise RuntimeError("x, dout must be (batch, seqlen, dim) with channel stride 1 and one dtype")
+    w = weight.reshape(Dm, -1)
+    dx = torch.empty(Bsz, L, Dm, device=x.device, dtype=x.dtype)
+    dw = torch.zeros(Dm, w.shape[1], device=x.device, dtype=torch.float32)
+    db = torch.zeros(Dm, device=x.device, dtype=torch.float32) if bias is not None else None
+    P = _lib.ConvBwdParams()
+    P.batch, P.dim, P.seqlen, P.width = Bsz, Dm, L, w.shape[1]
+    P.silu_activation, P.io_dtype, P.w_dtype, P.flags = int(bool(silu)), _lib.dtype_id(x), _lib.dtype_id(w), 0
+    P.x_batch_stride, P.x_l_stride = x.stride(0), x.stride(1)
+    P.dout_batch_stride, P.dout_l_stride = dout.stride(0), dout.stride(1)
+    P.dx_batch_stride, P.dx_l_stride = dx.stride(0), dx.stride(1)
+    P.weight_c_stride, P.weight_width_stride = w.stride(0), w.stride(1)
+    P.x, P.weight, P.bias, P.dout, P.dx = _lib.ptr(x), _lib.ptr(w), _lib.ptr(bias), _lib.ptr(dout), _lib.ptr(dx)
+    P.dweight, P.dbias = _lib.ptr(dw), _lib.ptr(db)
+    if bias is not None and bias.dtype != w.dtype:
+        raise RuntimeError("bias must have the dtype of weight")
+    if x_row_index is not None:
+        if x_row_index.dtype != torch.int32 or x_row_index.shape != (L,) or not x_row_index.is_contiguous():
+            raise RuntimeError("x_row_index must be a contiguous int32 (seqlen,) table")
+        P.x_row_index = _lib.ptr(x_row_index)
+    ws = _lib.workspace("zigma_causal_conv1d_bwd", P, dev)
+    _lib.call("zigma_causal_conv1d_bwd", P, dev)
+    del ws
+    return dx, dw, db

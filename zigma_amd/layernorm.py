@@ -61,11 +61,7 @@ def _flat(t):
     return t2 if t2.stride(-1) == 1 else t2.contiguous()
 
 
-def layer_norm_fn(x, weight, bias, residual=None, eps=1e-6, prenorm=False, residual_in_fp32=False,
-                  is_rms_norm=False):
-    """y = norm(x + residual) * weight + bias, statistics in float32.  Returns y, or (y, x + residual) when
-    `prenorm`; the returned residual has residual.dtype, else float32 if `residual_in_fp32`, else x.dtype —
-    the conventions of LayerNormFn.forward (layernorm.py:380-422)."""
+def _layer_norm_fwd(x, weight, bias, residual, eps, prenorm, residual_in_fp32, is_rms_norm):
     shape = x.shape
     x2 = _flat(x)
     r2 = None
@@ -77,10 +73,84 @@ def layer_norm_fn(x, weight, bias, residual=None, eps=1e-6, prenorm=False, resid
     w = weight.contiguous() if weight is not None else None
     b = bias.contiguous() if bias is not None else None
     y, res_out, _ = _norm_call(x2, w, b, r2, eps, is_rms_norm, res_dtype)
-    y = y.reshape(shape)
-    if not prenorm:
-        return y
-    return y, (res_out.reshape(shape) if res_out is not None else x)
+    return y.reshape(shape), (res_out.reshape(shape) if res_out is not None else x)
+
+
+def norm_bwd(xsum, weight, dy, dresidual_out, eps, is_rms, *, x_dtype, want_dx=True, want_dres=False, has_bias=False):
+    """zigma_add_norm_bwd (reference _layer_norm_bwd, layernorm.py:275-377).  xsum: the normalised tensor (..., cols);
+    returns dx (x_dtype) | None, dresidual (xsum.dtype) | None, dweight f32 | None, dbias f32 | None."""
+    dev = _lib.require_device(xsum, weight, dy, dresidual_out)
+    shape = xsum.shape
+    s2, dy2 = _flat(xsum), _flat(dy)
+    rows, cols = s2.shape
+    P = _lib.NormBwdParams()
+    P.rows, P.cols, P.is_rms, P.eps, P.flags = rows, cols, int(is_rms), float(eps), 0
+    P.x_dtype, P.res_dtype = _lib._DT[x_dtype], _lib.dtype_id(s2)
+    P.w_dtype = _lib.dtype_id(weight) if weight is not None else P.x_dtype
+    P.xsum, P.xsum_row_stride, P.dy, P.dy_row_stride = _lib.ptr(s2), s2.stride(0), _lib.ptr(dy2), dy2.stride(0)
+    if dy2.dtype != x_dtype:
+        raise RuntimeError("dy must have the dtype of the normalised output")
+    dx = dres = dw = db = None
+    if weight is not None:
+        P.weight = _lib.ptr(weight.contiguous())
+        dw = torch.zeros(cols, device=xsum.device, dtype=torch.float32)
+        P.dweight = _lib.ptr(dw)
+    if has_bias:
+        db = torch.zeros(cols, device=xsum.device, dtype=torch.float32)
+        P.dbias = _lib.ptr(db)
+    if dresidual_out is not None:
+        dr2 = _flat(dresidual_out)
+        if dr2.dtype != s2.dtype:
+            raise RuntimeError("dresidual_out must have the dtype of the residual stream")
+        P.dresidual_out, P.dres_out_row_stride = _lib.ptr(dr2), dr2.stride(0)
+    if want_dx:
+        dx = torch.empty(rows, cols, device=xsum.device, dtype=x_dtype)
+        P.dx, P.dx_row_stride = _lib.ptr(dx), dx.stride(0)
+    if want_dres:
+        dres = torch.empty(rows, cols, device=xsum.device, dtype=s2.dtype)
+        P.dresidual, P.dres_row_stride = _lib.ptr(dres), dres.stride(0)
+    ws = _lib.workspace("zigma_add_norm_bwd", P, dev)
+    _lib.call("zigma_add_norm_bwd", P, dev)
+    del ws
+    return (None if dx is None else dx.reshape(shape)), (None if dres is None else dres.reshape(shape)), dw, db
+
+
+class LayerNormFn(torch.autograd.Function):
+    """Autograd wrapper of the HIP forward / backward kernels; same contract as the reference's LayerNormFn
+    (layernorm.py:380-461): saves the normalised tensor (x, or x + residual), recomputes the statistics."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, residual, eps, prenorm, residual_in_fp32, is_rms_norm):
+        y, res_out = _layer_norm_fwd(x, weight, bias, residual, eps, prenorm, residual_in_fp32, is_rms_norm)
+        ctx.save_for_backward(res_out, weight)
+        ctx.eps, ctx.is_rms, ctx.prenorm = eps, is_rms_norm, prenorm
+        ctx.x_dtype, ctx.has_residual, ctx.has_bias = x.dtype, residual is not None, bias is not None
+        ctx.w_dtype = weight.dtype if weight is not None else None
+        return (y, res_out) if prenorm else y
+
+    @staticmethod
+    def backward(ctx, dy, *rest):
+        xsum, weight = ctx.saved_tensors
+        dres_out = rest[0] if ctx.prenorm and rest and rest[0] is not None else None
+        if dres_out is not None:
+            dres_out = dres_out.contiguous()
+        dx, dres, dw, db = norm_bwd(xsum, weight, dy.contiguous(), dres_out, ctx.eps, ctx.is_rms, x_dtype=ctx.x_dtype,
+                                    want_dx=True, want_dres=ctx.has_residual, has_bias=ctx.has_bias)
+        dw = None if dw is None else dw.to(ctx.w_dtype)
+        db = None if db is None else db.to(ctx.w_dtype)
+        return dx, dw, db, dres, None, None, None, None
+
+
+def layer_norm_fn(x, weight, bias, residual=None, eps=1e-6, prenorm=False, residual_in_fp32=False,
+                  is_rms_norm=False):
+    """y = norm(x + residual) * weight + bias, statistics in float32.  Returns y, or (y, x + residual) when
+    `prenorm`; the returned residual has residual.dtype, else float32 if `residual_in_fp32`, else x.dtype —
+    the conventions of LayerNormFn.forward (layernorm.py:380-422).  Differentiable (HIP backward) when autograd is
+    recording and any operand requires grad."""
+    if torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in (x, weight, bias, residual)):
+        return LayerNormFn.apply(x, weight, bias, residual, eps, prenorm, residual_in_fp32, is_rms_norm)
+    y, res_out = _layer_norm_fwd(x, weight, bias, residual, eps, prenorm, residual_in_fp32, is_rms_norm)
+    return (y, res_out) if prenorm else y
 
 
 def rms_norm_fn(x, weight, bias, residual=None, prenorm=False, residual_in_fp32=False, eps=1e-6):

@@ -246,8 +246,24 @@ class Block(nn.Module):
                 xa = modulate(layer_norm_fn(h, None, None, eps=self.norm_msa.eps), mod[3], mod[4])
                 h = h + mod[5].unsqueeze(1) * self.msa(xa, text=text, mask=None)
             return h, residual
+        if torch.is_grad_enabled() and (x.requires_grad or any(q.requires_grad for q in self.parameters())):
+            return self.forward_train(x, residual, c, text)
         pend, residual = self.forward_fused(Pending(x), residual, c, text)
         return pend.materialize(), residual
+
+    def forward_train(self, x, residual, c, text=None):
+        """Differentiable form (the reference's own composition, model_zigma.py:416-458): the add+norm, the Mamba inner
+        and the pre-attention LayerNorm are autograd Functions over the HIP forward AND backward kernels; modulate,
+        gating, projections and attention are torch ops."""
+        fn = rms_norm_fn if isinstance(self.norm, RMSNorm) else layer_norm_fn
+        x, residual = fn(x if residual is None else self.drop_path(x), self.norm.weight, self.norm.bias, residual=residual,
+                         prenorm=True, residual_in_fp32=self.residual_in_fp32, eps=self.norm.eps)
+        mod = self.adaLN_modulation(c).chunk(6 if self.has_text else 3, dim=1)
+        x = x + mod[2].unsqueeze(1) * self.mixer(modulate(x, mod[0], mod[1]))
+        if self.has_text:
+            xa = modulate(layer_norm_fn(x, None, None, eps=self.norm_msa.eps), mod[3], mod[4])
+            x = x + mod[5].unsqueeze(1) * self.msa(xa, text=text, mask=None)
+        return x, residual
 
 
 def create_block(d_model, ssm_cfg=None, has_text=False, norm_epsilon=1e-5, drop_path=0.0, rms_norm=False,
@@ -463,7 +479,10 @@ class ZigMa(nn.Module):
                              + self.temporal_pos_embedding.view(1, self.video_frames, 1, _D)).view(_B, _T, _D)
 
         residual = None
-        if self.fused_add_norm and not (self.training and torch.is_grad_enabled()) and self.use_pe != 3:
+        # autograd recording -> the per-block differentiable composition (HIP forward + backward kernels);
+        # otherwise (torch.no_grad(), the sampling path) the fully fused forward
+        needs_grad = torch.is_grad_enabled() and (hidden_states.requires_grad or c.requires_grad)
+        if self.fused_add_norm and not needs_grad and self.use_pe != 3:
             pend = Pending(hidden_states.contiguous())
             mods, kvs = self._batched_conditioning(c, y)
             for i, block in enumerate(self.blocks):

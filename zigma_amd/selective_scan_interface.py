@@ -12,14 +12,15 @@ plus `mamba_inner_tok`, the token-major fused form the ZigMa block uses on MI355
 the zigzag gather/scatter run on (B, L, C) activations straight out of / into the projection GEMMs,
 so none of the reference's transposes, `index_select`s or `cat`s exist.
 
-Backward (`selective_scan_cuda.bwd`) is the next scope row — these functions do not
-build an autograd graph.
+Backward: `scan_bwd_tok` binds zigma_selective_scan_bwd; `MambaInnerTokFn` is the autograd
+form of `mamba_inner_tok` (MambaInnerFn.backward, :367-434) that the blocks use when autograd is recording.  The
+(B, D, L)-layout entry points (`selective_scan_fn`, `mamba_inner_fn`) stay forward-only.
 """
 import torch
 import torch.nn.functional as F
 
 from . import _lib
-from .causal_conv1d_interface import causal_conv1d_raw
+from .causal_conv1d_interface import causal_conv1d_raw, conv_bwd_tok
 
 
 def _as_bgnl(M, name):
@@ -210,11 +211,77 @@ def scan_bwd_tok(u, delta, A, B, C, D, z, delta_bias, dout, out, delta_softplus,
         if t is not None and (t.dtype != torch.float32 or not t.is_contiguous()):
             raise RuntimeError(f"{nm} must be contiguous float32")
     P.D, P.delta_bias, P.dA, P.dD, P.ddelta_bias = _lib.ptr(D), _lib.ptr(delta_bias), _lib.ptr(dA), _lib.ptr(dD), _lib.ptr(dbias)
-    nbytes = _lib.lib().zigma_selective_scan_bwd_workspace_bytes(P)
-    ws = torch.empty(max(nbytes, 16), device=u.device, dtype=torch.uint8)
-    P.workspace, P.workspace_bytes = _lib.ptr(ws), nbytes
+    ws = _lib.workspace("zigma_selective_scan_bwd", P, dev)
     _lib.call("zigma_selective_scan_bwd", P, dev)
+    del ws
     return du, ddelta, dA, dB, dC, dD, dz, dbias
+
+
+class MambaInnerTokFn(torch.autograd.Function):
+    """Autograd form of the token-major Mamba inner (conv + SiLU -> x_proj -> dt_proj -> gated selective scan), operands
+    already in SCAN order (the caller gathers / scatters rows with index_select, which autograd differentiates).
+    Mirrors MambaInnerFn (selective_scan_interface.py:296-434) without its out_proj: forward saves u, x_dbl, delta and the
+    ungated scan output; backward = scan bwd kernel -> the two skinny GEMM pairs -> conv bwd kernel."""
+
+    @staticmethod
+    def forward(ctx, xz, conv_w, conv_b, x_proj_w, dt_proj_w, A, D, delta_bias):
+        Bsz, L, C2 = xz.shape
+        Di, R, N = C2 // 2, dt_proj_w.shape[1], A.shape[1]
+        w = conv_w.reshape(Di, -1)
+        x_half, z_half = xz[:, :, :Di], xz[:, :, Di:]
+        u = torch.empty(Bsz, L, Di, device=xz.device, dtype=xz.dtype)
+        causal_conv1d_raw(x_half.transpose(1, 2), w, conv_b, True, out=u.transpose(1, 2))
+        x_dbl = F.linear(u, x_proj_w)
+        delta = F.linear(x_dbl[:, :, :R], dt_proj_w)
+        Bm, Cm = x_dbl[:, :, R:R + N], x_dbl[:, :, R + N:R + 2 * N]
+        out = torch.empty(Bsz, L, Di, device=xz.device, dtype=xz.dtype)
+        y = torch.empty(Bsz, L, Di, device=xz.device, dtype=xz.dtype)
+        scan_raw(u.transpose(1, 2), delta.transpose(1, 2), A, Bm.transpose(1, 2).unsqueeze(1),
+                 Cm.transpose(1, 2).unsqueeze(1), D, z_half.transpose(1, 2), delta_bias, True,
+                 out=out.transpose(1, 2), out_z=y.transpose(1, 2))
+        ctx.save_for_backward(xz, conv_w, conv_b, x_proj_w, dt_proj_w, A, D, delta_bias, u, x_dbl, delta, out)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        xz, conv_w, conv_b, x_proj_w, dt_proj_w, A, D, delta_bias, u, x_dbl, delta, out = ctx.saved_tensors
+        Bsz, L, C2 = xz.shape
+        Di, R, N = C2 // 2, dt_proj_w.shape[1], A.shape[1]
+        x_half, z_half = xz[:, :, :Di], xz[:, :, Di:]
+        dy = dy.contiguous()
+        dx_dbl = torch.empty(Bsz, L, R + 2 * N, device=xz.device, dtype=torch.float32)
+        du, ddelta, dA, _, _, dD, dz, dbias = scan_bwd_tok(
+            u, delta, A, x_dbl[:, :, R:R + N], x_dbl[:, :, R + N:R + 2 * N], D, z_half, delta_bias, dy, out, True,
+            dB=dx_dbl[:, :, R:R + N], dC=dx_dbl[:, :, R + N:])
+        dd2 = ddelta.reshape(-1, Di)
+        dx_dbl[:, :, :R] = (dd2 @ dt_proj_w).reshape(Bsz, L, R)                  # d(x_dbl[:, :R]) = ddelta @ W_dt
+        d_dt_w = dd2.t() @ x_dbl.reshape(-1, R + 2 * N)[:, :R]                     # (Di, R)
+        dxd = dx_dbl.to(xz.dtype).reshape(-1, R + 2 * N)
+        du = du + (dxd @ x_proj_w).reshape(Bsz, L, Di)                             # x_dbl = u @ W_x^T
+        d_x_w = dxd.t() @ u.reshape(-1, Di)                                        # (R + 2N, Di)
+        dxh, d_cw, d_cb = conv_bwd_tok(x_half, conv_w, conv_b, du, True)
+        dxz = torch.cat([dxh, dz], dim=-1)
+        return (dxz, d_cw.to(conv_w.dtype).reshape(conv_w.shape), None if d_cb is None else d_cb.to(conv_b.dtype),
+                d_x_w.to(x_proj_w.dtype), d_dt_w.to(dt_proj_w.dtype), dA.to(A.dtype), dD.to(D.dtype),
+                None if dbias is None else dbias.to(delta_bias.dtype))
+
+
+def _inverse_table(rows):
+    inv = torch.empty_like(rows, dtype=torch.long)
+    inv[rows.long()] = torch.arange(rows.numel(), device=rows.device)
+    return inv
+
+
+def mamba_inner_tok_train(xz, conv1d_weight, conv1d_bias, x_proj_weight, delta_proj_weight, A, D, delta_bias, *,
+                          perm=None, out_rows=None):
+    """Differentiable mamba_inner_tok: rows gathered / scattered with index_select around MambaInnerTokFn."""
+    if D is None or delta_bias is None:
+        raise RuntimeError("the differentiable path expects D and delta_bias (ZigMa always has them)")
+    xs = xz if perm is None else xz.index_select(1, perm.long())
+    y = MambaInnerTokFn.apply(xs.contiguous(), conv1d_weight, conv1d_bias, x_proj_weight, delta_proj_weight, A, D, delta_bias)
+    if perm is None:
+        return y
+    return y.index_select(1, _inverse_table(perm if out_rows is None else out_rows))     # y_tok[rows[k]] = y'[k]
 
 
 def selective_scan_cuda_fwd(u, delta, A, B, C, D_, z_, delta_bias_, delta_softplus):
@@ -282,6 +349,12 @@ def mamba_inner_tok(xz, conv1d_weight, conv1d_bias, x_proj_weight, delta_proj_we
     """
     if xz.dim() != 3 or xz.stride(2) != 1:
         raise RuntimeError("xz must be (batch, seqlen, 2*d_inner) with contiguous channels")
+    if torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in (
+            xz, conv1d_weight, conv1d_bias, x_proj_weight, delta_proj_weight, A, D, delta_bias)):
+        if B_proj_bias is not None or C_proj_bias is not None or not delta_softplus or out is not None:
+            raise NotImplementedError("differentiable mamba_inner_tok: no B/C projection bias, softplus on, no out=")
+        return mamba_inner_tok_train(xz, conv1d_weight, conv1d_bias, x_proj_weight, delta_proj_weight, A, D, delta_bias,
+                                     perm=perm, out_rows=out_rows)
     Bsz, L, C2 = xz.shape
     Di = C2 // 2
     R = delta_proj_weight.shape[1]
