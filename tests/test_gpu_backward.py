@@ -223,3 +223,28 @@ def test_training_step_bf16_runs_and_decreases_loss():
         opt.step()
         losses.append(float(loss.detach()))
     assert all(np.isfinite(losses)) and losses[-1] < losses[0], losses
+
+
+def test_extension_shim_backward_entry_points():
+    """selective_scan_cuda.bwd / causal_conv1d_cuda.causal_conv1d_bwd with the reference's (B, D, L) operands and return
+    conventions (what the reference's SelectiveScanFn.backward / CausalConv1dFn.backward call)."""
+    from zigma_amd import extension_shims
+    ss, cc = extension_shims.install()
+    g = load_golden("bwd_scan_full.npz")
+    c = bwd_cases.scan_inputs("bwd_scan_full")
+    dev = lambda k: None if c[k] is None else c[k].to(DEV)
+    u, delta, A, D, z, db, dout = (dev(k) for k in ("u", "delta", "A", "D", "z", "delta_bias", "dout"))
+    Bm, Cm = dev("B").unsqueeze(1), dev("C").unsqueeze(1)
+    out, x, out_z = ss.fwd(u, delta, A, Bm, Cm, D, z, db, True)
+    dz_buf = torch.empty_like(z)
+    du, ddelta, dA, dB, dC, dD, dbias, dz, oz = ss.bwd(u, delta, A, Bm, Cm, D, z, db, dout, x, out, dz_buf, True, True)
+    assert dz.data_ptr() == dz_buf.data_ptr() and dB.shape == Bm.shape and dB.dtype == torch.float32
+    assert torch.allclose(oz, out_z, rtol=1e-5, atol=1e-6)
+    for got, key in ((du, "du"), (ddelta, "ddelta"), (dA, "dA"), (dB[:, 0], "dB"), (dC[:, 0], "dC"), (dD, "dD"),
+                     (dbias, "ddelta_bias"), (dz, "dz")):
+        assert rel_err(N(got), g[key]) < 5e-5, key
+    gc = load_golden("bwd_conv_silu.npz")
+    dx, dw, dbb = cc.causal_conv1d_bwd(T(gc["x"]), T(gc["weight"]), T(gc["bias"]), T(gc["dout"]), None, True)
+    assert dx.shape == gc["dx"].shape and rel_err(N(dx), gc["dx"]) < 2e-5 and rel_err(N(dw), gc["dweight"]) < 2e-5
+    with pytest.raises(NotImplementedError):
+        cc.causal_conv1d_update(None)

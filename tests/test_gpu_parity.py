@@ -410,7 +410,7 @@ def test_extension_shims_conventions():
     with pytest.raises(RuntimeError):
         ss.fwd(u, delta, torch.complex(A, A), Bm, Cm, None, None, None, False)
     with pytest.raises(NotImplementedError):
-        ss.bwd()
+        cc.causal_conv1d_update()
 
 
 def test_empty_inputs():
