@@ -236,6 +236,10 @@ typedef struct zigma_scan_bwd_params {
     float *ddelta_bias;      /* required iff delta_bias != NULL */
     void *workspace;
     int64_t workspace_bytes;
+    /* optional int32[seqlen] row tables, the forward's own (zigma_scan_params_t): scan position k reads z from / writes dz
+     * to row z_row_index[k], and reads out / dout from row out_row_index[k].  NULL = row k. */
+    const int32_t *z_row_index;
+    const int32_t *out_row_index;
 } zigma_scan_bwd_params_t;
 
 int64_t zigma_selective_scan_bwd_workspace_bytes(const zigma_scan_bwd_params_t *p);

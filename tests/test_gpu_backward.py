@@ -248,3 +248,32 @@ def test_extension_shim_backward_entry_points():
     assert dx.shape == gc["dx"].shape and rel_err(N(dx), gc["dx"]) < 2e-5 and rel_err(N(dw), gc["dweight"]) < 2e-5
     with pytest.raises(NotImplementedError):
         cc.causal_conv1d_update(None)
+
+
+def test_mamba_inner_tok_row_tables_match_explicit_gather_scatter():
+    """Row tables fused into the forward AND backward kernels (gather table perm, write-back table out_rows that is NOT its
+    inverse, as in the video temporal layers) vs the same op on explicitly gathered rows + an explicit scatter."""
+    from zigma_amd.selective_scan_interface import mamba_inner_tok
+    g = torch.Generator(device="cpu").manual_seed(9)
+    Bsz, L, Di, R, Nst = 2, 48, 128, 8, 16
+    mk = lambda *s, sc=1.0: (torch.randn(*s, generator=g) * sc).to(DEV).requires_grad_(True)
+    xz, cw, cb = mk(Bsz, L, 2 * Di), mk(Di, 1, 4, sc=0.5), mk(Di, sc=0.1)
+    xw, dw = mk(R + 2 * Nst, Di, sc=Di ** -0.5), mk(Di, R, sc=R ** -0.5)
+    A = (-torch.exp(torch.randn(Di, Nst, generator=g) * 0.5)).to(DEV).requires_grad_(True)
+    D, db = mk(Di), (torch.rand(Di, generator=g) * 0.5).to(DEV).requires_grad_(True)
+    perm = torch.randperm(L, generator=g).to(DEV, torch.int32)
+    out_rows = torch.randperm(L, generator=g).to(DEV, torch.int32)
+    wgt = torch.randn(Bsz, L, Di, generator=g).to(DEV)
+    leaves = (xz, cw, cb, xw, dw, A, D, db)
+
+    y1 = mamba_inner_tok(xz, cw, cb, xw, dw, A, D, db, perm=perm, out_rows=out_rows)
+    (y1 * wgt).sum().backward()
+    g1 = [t.grad.clone() for t in leaves]
+    for t in leaves:
+        t.grad = None
+    ys = mamba_inner_tok(xz.index_select(1, perm.long()), cw, cb, xw, dw, A, D, db)      # scan order in, scan order out
+    y2 = torch.zeros_like(ys).index_copy(1, out_rows.long(), ys)                          # y_tok[out_rows[k]] = y'[k]
+    (y2 * wgt).sum().backward()
+    assert torch.allclose(y1, y2, rtol=1e-5, atol=1e-6)
+    for a, t in zip(g1, leaves):
+        assert rel_err(N(a), N(t.grad)) < 1e-5

@@ -75,7 +75,7 @@ class ScanBwdParams(C.Structure):
                     "dB_l_stride", "dC_batch_stride", "dC_dstate_stride", "dC_l_stride")]
                 + [(n, vp) for n in ("u", "delta", "A", "B", "C", "D", "delta_bias", "z", "out", "dout", "du", "ddelta",
                                      "dz", "dA", "dB", "dC", "dD", "ddelta_bias", "workspace")]
-                + [("workspace_bytes", i64)])
+                + [("workspace_bytes", i64), ("z_row_index", vp), ("out_row_index", vp)])
 
 
 class ConvBwdParams(C.Structure):

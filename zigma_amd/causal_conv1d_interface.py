@@ -58,7 +58,7 @@ def causal_conv1d_fn(x, weight, bias=None, activation=None):
     return causal_conv1d_raw(x, weight, bias, activation in ["silu", "swish"])
 
 
-def conv_bwd_tok(x, weight, bias, dout, silu, x_row_index=None):
+def conv_bwd_tok(x, weight, bias, dout, silu, x_row_index=None, dx=None):
     """Backward of the token-major causal conv (zigma_causal_conv1d_bwd; reference causal_conv1d_cuda.causal_conv1d_bwd,
     causal_conv1d.cpp:191-283).  x, dout: (batch, seqlen, dim), channel stride 1; dout in SCAN order; x is read through
     x_row_index as in the forward and dx is scattered back through it.  Returns dx (dtype of x), dweight (dim, width) f32,
@@ -68,7 +68,10 @@ def conv_bwd_tok(x, weight, bias, dout, silu, x_row_index=None):
     if dout.shape != x.shape or x.stride(2) != 1 or dout.stride(2) != 1 or dout.dtype != x.dtype:
         raise RuntimeError("x, dout must be (batch, seqlen, dim) with channel stride 1 and one dtype")
     w = weight.reshape(Dm, -1)
-    dx = torch.empty(Bsz, L, Dm, device=x.device, dtype=x.dtype)
+    if dx is None:
+        dx = torch.empty(Bsz, L, Dm, device=x.device, dtype=x.dtype)
+    elif dx.shape != x.shape or dx.stride(2) != 1 or dx.dtype != x.dtype:
+        raise RuntimeError("dx must be (batch, seqlen, dim) with channel stride 1 and the dtype of x")
     dw = torch.zeros(Dm, w.shape[1], device=x.device, dtype=torch.float32)
     db = torch.zeros(Dm, device=x.device, dtype=torch.float32) if bias is not None else None
     P = _lib.ConvBwdParams()

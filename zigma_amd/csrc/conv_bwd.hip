@@ -125,15 +125,23 @@ __global__ __launch_bounds__(64) void conv_bwd_tok_kernel(const zigma_conv_bwd_p
     }
 }
 
-__global__ void conv_bwd_finish(const zigma_conv_bwd_params_t p, const float *ws, int n_parts) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;      // (c, t')  t' in [0, W]
-    const int W1 = p.width + 1;
-    if (i >= p.dim * W1) return;
-    const int c = i / W1, t = i % W1;
+// one block per 64 (channel, tap) entries: 4 waves each add every 4th partial, then fold
+__global__ __launch_bounds__(256) void conv_bwd_finish(const zigma_conv_bwd_params_t p, const float *ws, int n_parts) {
+    __shared__ float s_acc[4][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int W1 = p.width + 1, total = p.dim * W1;
+    const int i = blockIdx.x * 64 + lane;                     // (c, t')  t' in [0, W]
     float acc = 0.f;
-    for (int q = 0; q < n_parts; ++q) acc += ws[(static_cast<int64_t>(q) * p.dim + c) * W1 + t];
-    if (t < p.width) p.dweight[c * p.width + t] = acc;
-    else if (p.dbias) p.dbias[c] = acc;
+    if (i < total)
+        for (int q = wave; q < n_parts; q += 4) acc += ws[static_cast<int64_t>(q) * total + i];
+    s_acc[wave][lane] = acc;
+    __syncthreads();
+    if (wave == 0 && i < total) {
+        acc = (s_acc[0][lane] + s_acc[1][lane]) + (s_acc[2][lane] + s_acc[3][lane]);
+        const int c = i / W1, t = i % W1;
+        if (t < p.width) p.dweight[c * p.width + t] = acc;
+        else if (p.dbias) p.dbias[c] = acc;
+    }
 }
 
 template <typename IO, typename WT>
@@ -186,7 +194,7 @@ extern "C" int zigma_causal_conv1d_bwd(const zigma_conv_bwd_params_t *pp, void *
         ZIGMA_DISPATCH_DTYPE(p.w_dtype, WT, { launch_conv_bwd<IO, WT>(p, n_seg, stream); })
     })
     const int n = p.dim * (p.width + 1);
-    hipLaunchKernelGGL(conv_bwd_finish, dim3((n + 255) / 256), dim3(256), 0, stream, p, reinterpret_cast<const float *>(p.workspace),
+    hipLaunchKernelGGL(conv_bwd_finish, dim3((n + 63) / 64), dim3(256), 0, stream, p, reinterpret_cast<const float *>(p.workspace),
                        n_seg * p.batch);
     set_last_kernel("conv_bwd_tok");
     return check_launch();

@@ -20,7 +20,7 @@ __device__ __forceinline__ float nb_wave_sum(float v) {
     return v;
 }
 
-constexpr int kNbWaves = 4, kNbMaxWg = 1024;
+constexpr int kNbWaves = 4, kNbMaxWg = 512;
 
 template <typename XT, typename RT, typename WT, int ITERS>
 __global__ __launch_bounds__(64 * kNbWaves) void add_norm_bwd_kernel(const zigma_norm_bwd_params_t p, float *ws) {
@@ -94,14 +94,22 @@ __global__ __launch_bounds__(64 * kNbWaves) void add_norm_bwd_kernel(const zigma
     }
 }
 
-__global__ void add_norm_bwd_finish(const zigma_norm_bwd_params_t p, const float *ws, int n_parts) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;     // (which, c)
-    if (i >= 2 * p.cols) return;
-    const int which = i / p.cols, c = i % p.cols;
+// one block per 64 columns of dweight or dbias: 4 waves each add every 4th partial (coalesced 256-byte reads), then fold
+__global__ __launch_bounds__(256) void add_norm_bwd_finish(const zigma_norm_bwd_params_t p, const float *ws, int n_parts) {
+    __shared__ float s_acc[4][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int blocks_per = (p.cols + 63) / 64;
+    const int which = blockIdx.x / blocks_per, c = (blockIdx.x % blocks_per) * 64 + lane;
     float acc = 0.f;
-    for (int q = 0; q < n_parts; ++q) acc += ws[(static_cast<int64_t>(q) * 2 + which) * p.cols + c];
-    if (which == 0) { if (p.dweight) p.dweight[c] = acc; }
-    else if (p.dbias) p.dbias[c] = acc;
+    if (c < p.cols)
+        for (int q = wave; q < n_parts; q += 4) acc += ws[(static_cast<int64_t>(q) * 2 + which) * p.cols + c];
+    s_acc[wave][lane] = acc;
+    __syncthreads();
+    if (wave == 0 && c < p.cols) {
+        acc = (s_acc[0][lane] + s_acc[1][lane]) + (s_acc[2][lane] + s_acc[3][lane]);
+        if (which == 0) { if (p.dweight) p.dweight[c] = acc; }
+        else if (p.dbias) p.dbias[c] = acc;
+    }
 }
 
 static int nb_grid(const zigma_norm_bwd_params_t &p) {
@@ -119,7 +127,7 @@ static int launch_norm_bwd(const zigma_norm_bwd_params_t &p, hipStream_t stream)
     else if (p.cols <= 64 * 32) ZIGMA_NB(32);
     else return ZIGMA_ERR_SHAPE;
 #undef ZIGMA_NB
-    hipLaunchKernelGGL(add_norm_bwd_finish, dim3((2 * p.cols + 255) / 256), dim3(256), 0, stream, p, ws, grid * kNbWaves);
+    hipLaunchKernelGGL(add_norm_bwd_finish, dim3(2 * ((p.cols + 63) / 64)), dim3(256), 0, stream, p, ws, grid * kNbWaves);
     set_last_kernel("add_norm_bwd");
     return check_launch();
 }

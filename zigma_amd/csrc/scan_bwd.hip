@@ -142,12 +142,20 @@ __global__ __launch_bounds__(64 * NW, 2) void scan_bwd_kernel(const zigma_scan_b
     for (int t = n_tiles - 1; t >= 0; --t) {
         // ---- prologue: own rows -------------------------------------------------------------------------------
         float dvr[RPT], ur[RPT], gr[RPT], sgr[RPT];
+        int zi = 0, oi = 0;                       // row tables of this wave's rows: lane i (mod RPT) <- entry of row i
+        {
+            const int kt = clampk(t * LT + wave * RPT + (lane & (RPT - 1)));
+            if (p.z_row_index) zi = p.z_row_index[kt];
+            if (p.out_row_index) oi = p.out_row_index[kt];
+        }
 #pragma unroll
         for (int i = 0; i < RPT; ++i) {
             const int row = wave * RPT + i, k = t * LT + row, kk = clampk(k);
+            const int zrow = p.z_row_index ? __builtin_amdgcn_readlane(zi, i) : kk;
+            const int orow = p.out_row_index ? __builtin_amdgcn_readlane(oi, i) : kk;
             const float uf = to_float<IO>(buf_ld<IO>(u_rs, lane_off, kk * u_ls));
             const float draw = to_float<IO>(buf_ld<IO>(d_rs, lane_off, kk * d_ls)) + bias;
-            const float dof = to_float<IO>(buf_ld<IO>(do_rs, lane_off, kk * do_ls));
+            const float dof = to_float<IO>(buf_ld<IO>(do_rs, lane_off, orow * do_ls));
             float dv = draw, sg = 1.f;
             if (sp_on) {
                 dv = softplus20(draw);
@@ -155,12 +163,12 @@ __global__ __launch_bounds__(64 * NW, 2) void scan_bwd_kernel(const zigma_scan_b
             }
             float g = dof;
             if (has_z) {
-                const float zf = to_float<IO>(buf_ld<IO>(z_rs, lane_off, kk * z_ls));
-                const float yf = to_float<IO>(buf_ld<IO>(o_rs, lane_off, kk * o_ls));
+                const float zf = to_float<IO>(buf_ld<IO>(z_rs, lane_off, zrow * z_ls));
+                const float yf = to_float<IO>(buf_ld<IO>(o_rs, lane_off, orow * o_ls));
                 const float sz = fast_rcp(1.f + fast_exp2(-zf * kLog2e));
                 g = dof * zf * sz;
                 const float dz = dof * yf * sz * (1.f + zf * (1.f - sz));
-                if (k < L) buf_st<IO>(from_float<IO>(dz), dz_rs, lane_off, k * dz_ls);
+                if (k < L) buf_st<IO>(from_float<IO>(dz), dz_rs, lane_off, zrow * dz_ls);
             }
             const bool live = k < L;
             dvr[i] = live ? dv : 0.f; ur[i] = live ? uf : 0.f; gr[i] = live ? g : 0.f; sgr[i] = sg;

@@ -163,13 +163,17 @@ def dt_proj_softplus(x_dbl, dt_rank, weight, bias=None, softplus=True):
     return out.reshape(*lead, n)
 
 
-def scan_bwd_tok(u, delta, A, B, C, D, z, delta_bias, dout, out, delta_softplus, *, dB=None, dC=None):
+def scan_bwd_tok(u, delta, A, B, C, D, z, delta_bias, dout, out, delta_softplus, *, dB=None, dC=None, dz=None,
+                 z_row_index=None, out_row_index=None):
     """Backward of the token-major selective scan (zigma_selective_scan_bwd; reference selective_scan_cuda.bwd,
     selective_scan.cpp:338-492).
 
     u, delta, z, out, dout: (batch, seqlen, dim), channel stride 1; out = the forward's UNGATED y (only with z).
     B, C: (batch, seqlen, dstate)-shaped views (any strides), same dtype.  A (dim, dstate) f32, D / delta_bias f32.
     dB, dC: optional preallocated float32 (batch, seqlen, dstate) views to write into (e.g. columns of d(x_dbl)).
+    dz: optional preallocated (batch, seqlen, dim) view (e.g. the z half of d(xz)).
+    z_row_index / out_row_index: the forward's int32 row tables — z / dz live at row z_row_index[k], out / dout at row
+    out_row_index[k] of their tensors (token order) while u, delta, B, C, du, ddelta, dB, dC are in scan order.
     Returns du, ddelta, dA, dB, dC, dD, dz, ddelta_bias (None where the input was None); du/ddelta/dz in the input dtype,
     the rest float32."""
     dev = _lib.require_device(u, delta, A, B, C, D, z, delta_bias, dout, out)
@@ -185,7 +189,10 @@ def scan_bwd_tok(u, delta, A, B, C, D, z, delta_bias, dout, out, delta_softplus,
     if z is not None and out is None:
         raise RuntimeError("the gated backward needs the forward's ungated `out`")
     du, ddelta = torch.empty_like(u, memory_format=torch.contiguous_format), torch.empty_like(u, memory_format=torch.contiguous_format)
-    dz = torch.empty_like(u, memory_format=torch.contiguous_format) if z is not None else None
+    if z is not None and dz is None:
+        dz = torch.empty_like(u, memory_format=torch.contiguous_format)
+    if dz is not None and (dz.shape != u.shape or dz.stride(2) != 1 or dz.dtype != u.dtype):
+        raise RuntimeError("dz must be (batch, seqlen, dim) with channel stride 1 and the dtype of u")
     f32 = dict(device=u.device, dtype=torch.float32)
     dA = torch.zeros(Dm, N, **f32)
     dB = torch.empty(Bsz, L, N, **f32) if dB is None else dB
@@ -211,6 +218,11 @@ def scan_bwd_tok(u, delta, A, B, C, D, z, delta_bias, dout, out, delta_softplus,
         if t is not None and (t.dtype != torch.float32 or not t.is_contiguous()):
             raise RuntimeError(f"{nm} must be contiguous float32")
     P.D, P.delta_bias, P.dA, P.dD, P.ddelta_bias = _lib.ptr(D), _lib.ptr(delta_bias), _lib.ptr(dA), _lib.ptr(dD), _lib.ptr(dbias)
+    for name, tab in (("z_row_index", z_row_index), ("out_row_index", out_row_index)):
+        if tab is not None:
+            if tab.dtype != torch.int32 or tab.shape != (L,) or not tab.is_contiguous():
+                raise RuntimeError(f"{name} must be a contiguous int32 (seqlen,) table")
+            setattr(P, name, _lib.ptr(tab))
     ws = _lib.workspace("zigma_selective_scan_bwd", P, dev)
     _lib.call("zigma_selective_scan_bwd", P, dev)
     del ws
@@ -218,19 +230,20 @@ def scan_bwd_tok(u, delta, A, B, C, D, z, delta_bias, dout, out, delta_softplus,
 
 
 class MambaInnerTokFn(torch.autograd.Function):
-    """Autograd form of the token-major Mamba inner (conv + SiLU -> x_proj -> dt_proj -> gated selective scan), operands
-    already in SCAN order (the caller gathers / scatters rows with index_select, which autograd differentiates).
-    Mirrors MambaInnerFn (selective_scan_interface.py:296-434) without its out_proj: forward saves u, x_dbl, delta and the
-    ungated scan output; backward = scan bwd kernel -> the two skinny GEMM pairs -> conv bwd kernel."""
+    """Autograd form of the token-major Mamba inner (conv + SiLU -> x_proj -> dt_proj -> gated selective scan) with the
+    zigzag reordering fused into the kernels' row tables in BOTH directions (no index_select / index_add / cat):
+    forward  = conv (x_row_index) -> GEMMs -> scan (z_row_index, out_row_index), saving u, x_dbl, delta and the ungated y;
+    backward = scan bwd (same tables; dz lands in token order) -> the two skinny GEMM pairs -> conv bwd (dx scattered
+    through x_row_index).  Mirrors MambaInnerFn (selective_scan_interface.py:296-434) without its out_proj."""
 
     @staticmethod
-    def forward(ctx, xz, conv_w, conv_b, x_proj_w, dt_proj_w, A, D, delta_bias):
+    def forward(ctx, xz, conv_w, conv_b, x_proj_w, dt_proj_w, A, D, delta_bias, perm, out_rows):
         Bsz, L, C2 = xz.shape
         Di, R, N = C2 // 2, dt_proj_w.shape[1], A.shape[1]
         w = conv_w.reshape(Di, -1)
         x_half, z_half = xz[:, :, :Di], xz[:, :, Di:]
         u = torch.empty(Bsz, L, Di, device=xz.device, dtype=xz.dtype)
-        causal_conv1d_raw(x_half.transpose(1, 2), w, conv_b, True, out=u.transpose(1, 2))
+        causal_conv1d_raw(x_half.transpose(1, 2), w, conv_b, True, out=u.transpose(1, 2), x_row_index=perm)
         x_dbl = F.linear(u, x_proj_w)
         delta = F.linear(x_dbl[:, :, :R], dt_proj_w)
         Bm, Cm = x_dbl[:, :, R:R + N], x_dbl[:, :, R + N:R + 2 * N]
@@ -238,8 +251,9 @@ class MambaInnerTokFn(torch.autograd.Function):
         y = torch.empty(Bsz, L, Di, device=xz.device, dtype=xz.dtype)
         scan_raw(u.transpose(1, 2), delta.transpose(1, 2), A, Bm.transpose(1, 2).unsqueeze(1),
                  Cm.transpose(1, 2).unsqueeze(1), D, z_half.transpose(1, 2), delta_bias, True,
-                 out=out.transpose(1, 2), out_z=y.transpose(1, 2))
+                 out=out.transpose(1, 2), out_z=y.transpose(1, 2), z_row_index=perm, out_row_index=out_rows)
         ctx.save_for_backward(xz, conv_w, conv_b, x_proj_w, dt_proj_w, A, D, delta_bias, u, x_dbl, delta, out)
+        ctx.perm, ctx.out_rows = perm, out_rows
         return y
 
     @staticmethod
@@ -249,39 +263,31 @@ class MambaInnerTokFn(torch.autograd.Function):
         Di, R, N = C2 // 2, dt_proj_w.shape[1], A.shape[1]
         x_half, z_half = xz[:, :, :Di], xz[:, :, Di:]
         dy = dy.contiguous()
+        dxz = torch.empty_like(xz)
         dx_dbl = torch.empty(Bsz, L, R + 2 * N, device=xz.device, dtype=torch.float32)
-        du, ddelta, dA, _, _, dD, dz, dbias = scan_bwd_tok(
+        du, ddelta, dA, _, _, dD, _, dbias = scan_bwd_tok(
             u, delta, A, x_dbl[:, :, R:R + N], x_dbl[:, :, R + N:R + 2 * N], D, z_half, delta_bias, dy, out, True,
-            dB=dx_dbl[:, :, R:R + N], dC=dx_dbl[:, :, R + N:])
+            dB=dx_dbl[:, :, R:R + N], dC=dx_dbl[:, :, R + N:], dz=dxz[:, :, Di:], z_row_index=ctx.perm,
+            out_row_index=ctx.out_rows)
         dd2 = ddelta.reshape(-1, Di)
         dx_dbl[:, :, :R] = (dd2 @ dt_proj_w).reshape(Bsz, L, R)                  # d(x_dbl[:, :R]) = ddelta @ W_dt
         d_dt_w = dd2.t() @ x_dbl.reshape(-1, R + 2 * N)[:, :R]                     # (Di, R)
         dxd = dx_dbl.to(xz.dtype).reshape(-1, R + 2 * N)
-        du = du + (dxd @ x_proj_w).reshape(Bsz, L, Di)                             # x_dbl = u @ W_x^T
+        du = torch.addmm(du.reshape(-1, Di), dxd, x_proj_w).reshape(Bsz, L, Di)    # x_dbl = u @ W_x^T
         d_x_w = dxd.t() @ u.reshape(-1, Di)                                        # (R + 2N, Di)
-        dxh, d_cw, d_cb = conv_bwd_tok(x_half, conv_w, conv_b, du, True)
-        dxz = torch.cat([dxh, dz], dim=-1)
+        _, d_cw, d_cb = conv_bwd_tok(x_half, conv_w, conv_b, du, True, ctx.perm, dx=dxz[:, :, :Di])
         return (dxz, d_cw.to(conv_w.dtype).reshape(conv_w.shape), None if d_cb is None else d_cb.to(conv_b.dtype),
                 d_x_w.to(x_proj_w.dtype), d_dt_w.to(dt_proj_w.dtype), dA.to(A.dtype), dD.to(D.dtype),
-                None if dbias is None else dbias.to(delta_bias.dtype))
-
-
-def _inverse_table(rows):
-    inv = torch.empty_like(rows, dtype=torch.long)
-    inv[rows.long()] = torch.arange(rows.numel(), device=rows.device)
-    return inv
+                None if dbias is None else dbias.to(delta_bias.dtype), None, None)
 
 
 def mamba_inner_tok_train(xz, conv1d_weight, conv1d_bias, x_proj_weight, delta_proj_weight, A, D, delta_bias, *,
                           perm=None, out_rows=None):
-    """Differentiable mamba_inner_tok: rows gathered / scattered with index_select around MambaInnerTokFn."""
+    """Differentiable mamba_inner_tok (same row-table semantics)."""
     if D is None or delta_bias is None:
         raise RuntimeError("the differentiable path expects D and delta_bias (ZigMa always has them)")
-    xs = xz if perm is None else xz.index_select(1, perm.long())
-    y = MambaInnerTokFn.apply(xs.contiguous(), conv1d_weight, conv1d_bias, x_proj_weight, delta_proj_weight, A, D, delta_bias)
-    if perm is None:
-        return y
-    return y.index_select(1, _inverse_table(perm if out_rows is None else out_rows))     # y_tok[rows[k]] = y'[k]
+    return MambaInnerTokFn.apply(xz, conv1d_weight, conv1d_bias, x_proj_weight, delta_proj_weight, A, D, delta_bias, perm,
+                                 perm if out_rows is None else out_rows)
 
 
 def selective_scan_cuda_fwd(u, delta, A, B, C, D_, z_, delta_bias_, delta_softplus):
