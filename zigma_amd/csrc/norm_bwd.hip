@@ -22,30 +22,59 @@ __device__ __forceinline__ float nb_wave_sum(float v) {
 
 constexpr int kNbWaves = 4, kNbMaxWg = 512;
 
-template <typename XT, typename RT, typename WT, int ITERS>
+// VEC consecutive columns per lane per iteration (8-16 byte accesses when VEC = 4)
+template <typename T, int VEC> __device__ __forceinline__ void nb_load(const void *base, int64_t idx, float (&f)[VEC]) {
+    if constexpr (VEC == 1) {
+        f[0] = ld<T>(base, idx);
+    } else if constexpr (T::id == ZIGMA_F32) {
+        const uint4 r = *reinterpret_cast<const uint4 *>(reinterpret_cast<const float *>(base) + idx);
+        f[0] = __uint_as_float(r.x); f[1] = __uint_as_float(r.y); f[2] = __uint_as_float(r.z); f[3] = __uint_as_float(r.w);
+    } else {
+        const uint2 r = *reinterpret_cast<const uint2 *>(reinterpret_cast<const uint16_t *>(base) + idx);
+        f[0] = to_float<T>(r.x & 0xffffu); f[1] = to_float<T>(r.x >> 16);
+        f[2] = to_float<T>(r.y & 0xffffu); f[3] = to_float<T>(r.y >> 16);
+    }
+}
+template <typename T, int VEC> __device__ __forceinline__ void nb_store(void *base, int64_t idx, const float (&f)[VEC]) {
+    if constexpr (VEC == 1) {
+        st<T>(base, idx, f[0]);
+    } else if constexpr (T::id == ZIGMA_F32) {
+        *reinterpret_cast<uint4 *>(reinterpret_cast<float *>(base) + idx) =
+            make_uint4(__float_as_uint(f[0]), __float_as_uint(f[1]), __float_as_uint(f[2]), __float_as_uint(f[3]));
+    } else {
+        *reinterpret_cast<uint2 *>(reinterpret_cast<uint16_t *>(base) + idx) =
+            make_uint2(from_float<T>(f[0]) | (uint32_t(from_float<T>(f[1])) << 16),
+                       from_float<T>(f[2]) | (uint32_t(from_float<T>(f[3])) << 16));
+    }
+}
+
+template <typename XT, typename RT, typename WT, int VEC, int ITERS>
 __global__ __launch_bounds__(64 * kNbWaves) void add_norm_bwd_kernel(const zigma_norm_bwd_params_t p, float *ws) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int gw = blockIdx.x * kNbWaves + wave, n_gw = gridDim.x * kNbWaves;
     const int cols = p.cols;
-    float dw[ITERS], db[ITERS], w[ITERS];
+    float dw[ITERS][VEC], db[ITERS][VEC], w[ITERS][VEC];
 #pragma unroll
     for (int it = 0; it < ITERS; ++it) {
-        const int c = it * 64 + lane;
-        dw[it] = 0.f; db[it] = 0.f;
-        w[it] = (p.weight && c < cols) ? ld<WT>(p.weight, c) : 1.f;
+        const int c = (it * 64 + lane) * VEC;
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) { dw[it][v] = 0.f; db[it][v] = 0.f; w[it][v] = 1.f; }
+        if (p.weight && c < cols) nb_load<WT, VEC>(p.weight, c, w[it]);
     }
     for (int64_t r = gw; r < p.rows; r += n_gw) {
-        float s[ITERS], dy[ITERS];
+        float s[ITERS][VEC], dy[ITERS][VEC];
         float sum = 0.f, sq = 0.f;
 #pragma unroll
         for (int it = 0; it < ITERS; ++it) {
-            const int c = it * 64 + lane;
-            s[it] = 0.f; dy[it] = 0.f;
+            const int c = (it * 64 + lane) * VEC;
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) { s[it][v] = 0.f; dy[it][v] = 0.f; }
             if (c < cols) {
-                s[it] = ld<RT>(p.xsum, r * p.xsum_row_stride + c);
-                dy[it] = ld<XT>(p.dy, r * p.dy_row_stride + c);
+                nb_load<RT, VEC>(p.xsum, r * p.xsum_row_stride + c, s[it]);
+                nb_load<XT, VEC>(p.dy, r * p.dy_row_stride + c, dy[it]);
             }
-            sum += s[it]; sq += s[it] * s[it];
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) { sum += s[it][v]; sq += s[it][v] * s[it][v]; }
         }
         float mean = 0.f, rstd;
         if (p.is_rms) {
@@ -55,41 +84,67 @@ __global__ __launch_bounds__(64 * kNbWaves) void add_norm_bwd_kernel(const zigma
             float var = 0.f;
 #pragma unroll
             for (int it = 0; it < ITERS; ++it) {
-                const int c = it * 64 + lane;
-                if (c < cols) { const float d = s[it] - mean; var += d * d; }
+                const int c = (it * 64 + lane) * VEC;
+                if (c < cols) {
+#pragma unroll
+                    for (int v = 0; v < VEC; ++v) { const float d = s[it][v] - mean; var += d * d; }
+                }
             }
             rstd = rsqrtf(nb_wave_sum(var) / cols + p.eps);
         }
         float c1 = 0.f, c2 = 0.f;
 #pragma unroll
         for (int it = 0; it < ITERS; ++it) {
-            const int c = it * 64 + lane;
-            const float xhat = c < cols ? (s[it] - mean) * rstd : 0.f;
-            const float wdy = dy[it] * w[it];
-            c1 += xhat * wdy; c2 += wdy;
-            dw[it] += dy[it] * xhat; db[it] += dy[it];
-            s[it] = xhat;
-            dy[it] = wdy;
+            const int c = (it * 64 + lane) * VEC;
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) {
+                const float xhat = c < cols ? (s[it][v] - mean) * rstd : 0.f;
+                const float wdy = dy[it][v] * w[it][v];
+                c1 += xhat * wdy; c2 += wdy;
+                dw[it][v] += dy[it][v] * xhat; db[it][v] += dy[it][v];
+                s[it][v] = xhat;
+                dy[it][v] = wdy;
+            }
         }
         c1 = nb_wave_sum(c1) / cols;
         c2 = p.is_rms ? 0.f : nb_wave_sum(c2) / cols;
 #pragma unroll
         for (int it = 0; it < ITERS; ++it) {
-            const int c = it * 64 + lane;
+            const int c = (it * 64 + lane) * VEC;
             if (c < cols) {
-                float ds = (dy[it] - s[it] * c1 - c2) * rstd;
-                if (p.dresidual_out) ds += ld<RT>(p.dresidual_out, r * p.dres_out_row_stride + c);
-                if (p.dx) st<XT>(p.dx, r * p.dx_row_stride + c, ds);
-                if (p.dresidual) st<RT>(p.dresidual, r * p.dres_row_stride + c, ds);
+                float ds[VEC];
+#pragma unroll
+                for (int v = 0; v < VEC; ++v) ds[v] = (dy[it][v] - s[it][v] * c1 - c2) * rstd;
+                if (p.dresidual_out) {
+                    float dr[VEC];
+                    nb_load<RT, VEC>(p.dresidual_out, r * p.dres_out_row_stride + c, dr);
+#pragma unroll
+                    for (int v = 0; v < VEC; ++v) ds[v] += dr[v];
+                }
+                if (p.dx) nb_store<XT, VEC>(p.dx, r * p.dx_row_stride + c, ds);
+                if (p.dresidual) nb_store<RT, VEC>(p.dresidual, r * p.dres_row_stride + c, ds);
             }
         }
     }
+    // fold the 4 waves' partials through LDS: one partial per WORKGROUP goes to the workspace
+    __shared__ float s_fold[kNbWaves][2][64 * VEC];
 #pragma unroll
     for (int it = 0; it < ITERS; ++it) {
-        const int c = it * 64 + lane;
-        if (c < cols) {
-            ws[(static_cast<int64_t>(gw) * 2 + 0) * cols + c] = dw[it];
-            ws[(static_cast<int64_t>(gw) * 2 + 1) * cols + c] = db[it];
+        const int c = (it * 64 + lane) * VEC;
+        __syncthreads();
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) {
+            s_fold[wave][0][lane * VEC + v] = dw[it][v];
+            s_fold[wave][1][lane * VEC + v] = db[it][v];
+        }
+        __syncthreads();
+        if (wave < 2 && c < cols) {
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) {
+                const int q = lane * VEC + v;
+                ws[(static_cast<int64_t>(blockIdx.x) * 2 + wave) * cols + c + v] =
+                    (s_fold[0][wave][q] + s_fold[1][wave][q]) + (s_fold[2][wave][q] + s_fold[3][wave][q]);
+            }
         }
     }
 }
@@ -121,13 +176,20 @@ template <typename XT, typename RT, typename WT>
 static int launch_norm_bwd(const zigma_norm_bwd_params_t &p, hipStream_t stream) {
     const int grid = nb_grid(p);
     float *ws = reinterpret_cast<float *>(p.workspace);
-#define ZIGMA_NB(I_) hipLaunchKernelGGL((add_norm_bwd_kernel<XT, RT, WT, I_>), dim3(grid), dim3(64 * kNbWaves), 0, stream, p, ws)
-    if (p.cols <= 64 * 4) ZIGMA_NB(4);
-    else if (p.cols <= 64 * 12) ZIGMA_NB(12);
-    else if (p.cols <= 64 * 32) ZIGMA_NB(32);
+    constexpr size_t xs = sizeof(typename XT::raw), rs = sizeof(typename RT::raw), wsz = sizeof(typename WT::raw);
+    auto al = [](const void *q, size_t a) { return q == nullptr || reinterpret_cast<uintptr_t>(q) % a == 0; };
+    const bool vec = p.cols % 4 == 0 && p.xsum_row_stride % 4 == 0 && p.dy_row_stride % 4 == 0 && p.dres_out_row_stride % 4 == 0 &&
+                     p.dx_row_stride % 4 == 0 && p.dres_row_stride % 4 == 0 && al(p.xsum, 4 * rs) && al(p.dy, 4 * xs) &&
+                     al(p.dresidual_out, 4 * rs) && al(p.dx, 4 * xs) && al(p.dresidual, 4 * rs) && al(p.weight, 4 * wsz);
+#define ZIGMA_NB(V_, I_) hipLaunchKernelGGL((add_norm_bwd_kernel<XT, RT, WT, V_, I_>), dim3(grid), dim3(64 * kNbWaves), 0, stream, p, ws)
+    if (vec && p.cols <= 256 * 3) ZIGMA_NB(4, 3);
+    else if (vec && p.cols <= 256 * 8) ZIGMA_NB(4, 8);
+    else if (p.cols <= 64 * 4) ZIGMA_NB(1, 4);
+    else if (p.cols <= 64 * 12) ZIGMA_NB(1, 12);
+    else if (p.cols <= 64 * 32) ZIGMA_NB(1, 32);
     else return ZIGMA_ERR_SHAPE;
 #undef ZIGMA_NB
-    hipLaunchKernelGGL(add_norm_bwd_finish, dim3(2 * ((p.cols + 63) / 64)), dim3(256), 0, stream, p, ws, grid * kNbWaves);
+    hipLaunchKernelGGL(add_norm_bwd_finish, dim3(2 * ((p.cols + 63) / 64)), dim3(256), 0, stream, p, ws, grid);
     set_last_kernel("add_norm_bwd");
     return check_launch();
 }
@@ -138,7 +200,7 @@ using namespace zigma;
 
 extern "C" int64_t zigma_add_norm_bwd_workspace_bytes(const zigma_norm_bwd_params_t *p) {
     if (!p || p->rows <= 0 || p->cols <= 0) return 0;
-    return static_cast<int64_t>(nb_grid(*p)) * kNbWaves * 2 * p->cols * static_cast<int64_t>(sizeof(float));
+    return static_cast<int64_t>(nb_grid(*p)) * 2 * p->cols * static_cast<int64_t>(sizeof(float));
 }
 
 extern "C" int zigma_add_norm_bwd(const zigma_norm_bwd_params_t *pp, void *stream_) {

@@ -93,13 +93,31 @@ __global__ __launch_bounds__(64 * NW, 2) void scan_bwd_kernel(const zigma_scan_b
 
     // ================================ phase 1: forward, checkpoints ================================================
     float h[4] = {0.f, 0.f, 0.f, 0.f};
+    // operands are fetched ONE TILE AHEAD and kept raw (widened where consumed): a workgroup never waits for a load it
+    // issued in the same tile (2 waves / SIMD cannot hide HBM latency by occupancy)
+    io_t pu[RPT], pd[RPT], pb[NG], pc[NG];
+    auto bc_raw = [&](rsrc_t rs, unsigned lane_base, int ls, int t, int g) {
+        const int k = clampk(t * LT + g * 4 + bc_s);
+        return buf_ld<IO>(rs, lane_base + static_cast<unsigned>(k * ls), 0);
+    };
+    auto fetch_fwd = [&](int t) {
+#pragma unroll
+        for (int i = 0; i < RPT; ++i) {
+            const int kk = clampk(t * LT + wave * RPT + i);
+            pu[i] = buf_ld<IO>(u_rs, lane_off, kk * u_ls);
+            pd[i] = buf_ld<IO>(d_rs, lane_off, kk * d_ls);
+        }
+#pragma unroll
+        for (int g = 0; g < NG; ++g) pb[g] = bc_raw(B_rs, B_lane, B_ls, t, g);
+    };
+    fetch_fwd(0);
 #pragma unroll 1
     for (int t = 0; t < n_tiles; ++t) {
 #pragma unroll
         for (int i = 0; i < RPT; ++i) {
-            const int row = wave * RPT + i, k = t * LT + row, kk = clampk(k);
-            const float uf = to_float<IO>(buf_ld<IO>(u_rs, lane_off, kk * u_ls));
-            float dv = to_float<IO>(buf_ld<IO>(d_rs, lane_off, kk * d_ls)) + bias;
+            const int row = wave * RPT + i, k = t * LT + row;
+            const float uf = to_float<IO>(pu[i]);
+            float dv = to_float<IO>(pd[i]) + bias;
             if (sp_on) dv = softplus20(dv);
             if (k >= L) dv = 0.f;
             s_dv[row][lane] = dv;
@@ -107,7 +125,8 @@ __global__ __launch_bounds__(64 * NW, 2) void scan_bwd_kernel(const zigma_scan_b
         }
         float Bf[NG];
 #pragma unroll
-        for (int g = 0; g < NG; ++g) Bf[g] = load_bc(B_rs, B_lane, B_ls, t, g);
+        for (int g = 0; g < NG; ++g) Bf[g] = to_float<IO>(pb[g]);
+        if (t + 1 < n_tiles) fetch_fwd(t + 1);
 #pragma unroll
         for (int j = 0; j < 4; ++j) ck[(static_cast<int64_t>(t) * N + n0 + j) * 64 + lane] = h[j];
         __syncthreads();
@@ -138,24 +157,54 @@ __global__ __launch_bounds__(64 * NW, 2) void scan_bwd_kernel(const zigma_scan_b
     const int r_half = lane >> 5, r_which = (lane >> 4) & 1, r_si = (lane >> 2) & 3, r_j = lane & 3;
     const float *red_src = &s_red[wave][r_which][r_si * kRedPitch + r_half * 32 * 4 + r_j];
 
+    io_t pdo[RPT], pz[RPT], po[RPT];
+    float h0n[4];
+    int zi_c = 0, oi_c = 0, zi_n = 0, oi_n = 0;   // row tables (lane i mod RPT <- row i of this wave) of the tile in the
+                                                  // prefetch registers / of the tile after it
+    auto load_tabs = [&](int t) {
+        const int kt = clampk(t * LT + wave * RPT + (lane & (RPT - 1)));
+        if (p.z_row_index) zi_n = p.z_row_index[kt];
+        if (p.out_row_index) oi_n = p.out_row_index[kt];
+    };
+    auto fetch_bwd = [&](int t) {                 // consumes (zi_n, oi_n) as the tables of tile t
+        zi_c = zi_n;
+        oi_c = oi_n;
+#pragma unroll
+        for (int i = 0; i < RPT; ++i) {
+            const int kk = clampk(t * LT + wave * RPT + i);
+            const int zrow = p.z_row_index ? __builtin_amdgcn_readlane(zi_c, i) : kk;
+            const int orow = p.out_row_index ? __builtin_amdgcn_readlane(oi_c, i) : kk;
+            pu[i] = buf_ld<IO>(u_rs, lane_off, kk * u_ls);
+            pd[i] = buf_ld<IO>(d_rs, lane_off, kk * d_ls);
+            pdo[i] = buf_ld<IO>(do_rs, lane_off, orow * do_ls);
+            if (has_z) {
+                pz[i] = buf_ld<IO>(z_rs, lane_off, zrow * z_ls);
+                po[i] = buf_ld<IO>(o_rs, lane_off, orow * o_ls);
+            }
+        }
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+            pb[g] = bc_raw(B_rs, B_lane, B_ls, t, g);
+            pc[g] = bc_raw(C_rs, C_lane, C_ls, t, g);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) h0n[j] = ck[(static_cast<int64_t>(t) * N + n0 + j) * 64 + lane];
+    };
+    load_tabs(n_tiles - 1);
+    fetch_bwd(n_tiles - 1);
+    if (n_tiles > 1) load_tabs(n_tiles - 2);
+
 #pragma unroll 1
     for (int t = n_tiles - 1; t >= 0; --t) {
-        // ---- prologue: own rows -------------------------------------------------------------------------------
+        // ---- prologue: own rows (operands of this tile are in the prefetch registers) ----------------------------
         float dvr[RPT], ur[RPT], gr[RPT], sgr[RPT];
-        int zi = 0, oi = 0;                       // row tables of this wave's rows: lane i (mod RPT) <- entry of row i
-        {
-            const int kt = clampk(t * LT + wave * RPT + (lane & (RPT - 1)));
-            if (p.z_row_index) zi = p.z_row_index[kt];
-            if (p.out_row_index) oi = p.out_row_index[kt];
-        }
 #pragma unroll
         for (int i = 0; i < RPT; ++i) {
             const int row = wave * RPT + i, k = t * LT + row, kk = clampk(k);
-            const int zrow = p.z_row_index ? __builtin_amdgcn_readlane(zi, i) : kk;
-            const int orow = p.out_row_index ? __builtin_amdgcn_readlane(oi, i) : kk;
-            const float uf = to_float<IO>(buf_ld<IO>(u_rs, lane_off, kk * u_ls));
-            const float draw = to_float<IO>(buf_ld<IO>(d_rs, lane_off, kk * d_ls)) + bias;
-            const float dof = to_float<IO>(buf_ld<IO>(do_rs, lane_off, orow * do_ls));
+            const int zrow = p.z_row_index ? __builtin_amdgcn_readlane(zi_c, i) : kk;
+            const float uf = to_float<IO>(pu[i]);
+            const float draw = to_float<IO>(pd[i]) + bias;
+            const float dof = to_float<IO>(pdo[i]);
             float dv = draw, sg = 1.f;
             if (sp_on) {
                 dv = softplus20(draw);
@@ -163,8 +212,8 @@ __global__ __launch_bounds__(64 * NW, 2) void scan_bwd_kernel(const zigma_scan_b
             }
             float g = dof;
             if (has_z) {
-                const float zf = to_float<IO>(buf_ld<IO>(z_rs, lane_off, zrow * z_ls));
-                const float yf = to_float<IO>(buf_ld<IO>(o_rs, lane_off, orow * o_ls));
+                const float zf = to_float<IO>(pz[i]);
+                const float yf = to_float<IO>(po[i]);
                 const float sz = fast_rcp(1.f + fast_exp2(-zf * kLog2e));
                 g = dof * zf * sz;
                 const float dz = dof * yf * sz * (1.f + zf * (1.f - sz));
@@ -179,11 +228,15 @@ __global__ __launch_bounds__(64 * NW, 2) void scan_bwd_kernel(const zigma_scan_b
         float Bf[NG], Cf[NG], h0[4];
 #pragma unroll
         for (int g = 0; g < NG; ++g) {
-            Bf[g] = load_bc(B_rs, B_lane, B_ls, t, g);
-            Cf[g] = load_bc(C_rs, C_lane, C_ls, t, g);
+            Bf[g] = to_float<IO>(pb[g]);
+            Cf[g] = to_float<IO>(pc[g]);
         }
 #pragma unroll
-        for (int j = 0; j < 4; ++j) h0[j] = ck[(static_cast<int64_t>(t) * N + n0 + j) * 64 + lane];
+        for (int j = 0; j < 4; ++j) h0[j] = h0n[j];
+        if (t > 0) {
+            fetch_bwd(t - 1);
+            if (t > 1) load_tabs(t - 2);
+        }
         __syncthreads();
 
         // ---- forward recompute of the 16 states -----------------------------------------------------------------
@@ -249,9 +302,15 @@ __global__ __launch_bounds__(64 * NW, 2) void scan_bwd_kernel(const zigma_scan_b
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            float acc = 0.f;
+            float rv[32];                                   // all reads in flight before the first add
 #pragma unroll
-            for (int q = 0; q < 32; ++q) acc += red_src[q * 4];
+            for (int q = 0; q < 32; ++q) rv[q] = red_src[q * 4];
+#pragma unroll
+            for (int w = 16; w > 0; w >>= 1) {
+#pragma unroll
+                for (int q = 0; q < w; ++q) rv[q] += rv[q + w];
+            }
+            float acc = rv[0];
             acc += __shfl_xor(acc, 32, 64);
             if (lane < 32) bc_out[(static_cast<int64_t>(t * LT + g * 4 + r_si) * 2 + r_which) * N + n0 + r_j] = acc;
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
