@@ -206,13 +206,28 @@ class ode:
         self.sampler_type = sampler_type
 
     def sample(self, x, model, **model_kwargs):
-        if isinstance(x, tuple):
-            raise NotImplementedError("zigma_amd: likelihood integration (tuple state) is out of scope")
-        device = x.device
-        ones = th.ones(x.size(0), device=device)
-
-        def _fn(t, x):
-            return self.drift(x, ones * t, model, **model_kwargs)
-
+        """x: Tensor -> Tensor(num_steps, *x.shape);  tuple of per-sample tensors (the likelihood ODE's (x, logp)) ->
+        tuple of such tensors.  A tuple state is integrated as ONE flattened (batch, sum of sizes) vector, like
+        torchdiffeq does (one shared step size and error norm)."""
+        is_tuple = isinstance(x, tuple)
+        device = x[0].device if is_tuple else x.device
         t = self.t.to(device)
-        return odeint(_fn, x, t, method=self.sampler_type, atol=[self.atol], rtol=[self.rtol])
+        if not is_tuple:
+            ones = th.ones(x.size(0), device=device)
+
+            def _fn(t, x):
+                return self.drift(x, ones * t, model, **model_kwargs)
+
+            return odeint(_fn, x, t, method=self.sampler_type, atol=[self.atol], rtol=[self.rtol])
+        bsz = x[0].size(0)
+        shapes = [xi.shape for xi in x]
+        sizes = [xi[0].numel() if xi.dim() > 1 else 1 for xi in x]
+        ones = th.ones(bsz, device=device)
+        pack = lambda parts: th.cat([q.reshape(bsz, -1) for q in parts], dim=1)
+        unpack = lambda y: tuple(q.reshape(sh) for q, sh in zip(th.split(y, sizes, dim=1), shapes))
+
+        def _fn_tuple(t, y):
+            return pack(self.drift(unpack(y), ones * t, model, **model_kwargs))
+
+        ys = odeint(_fn_tuple, pack(x), t, method=self.sampler_type, atol=[self.atol], rtol=[self.rtol])
+        return tuple(q.reshape((ys.shape[0],) + tuple(sh)) for q, sh in zip(th.split(ys, sizes, dim=2), shapes))

@@ -6,6 +6,7 @@ sample_acc.py:159-165,362); the likelihood sampler is a later scope row and rais
 """
 import enum
 
+import numpy as np
 import torch as th
 
 from . import path
@@ -43,6 +44,11 @@ class Transport:
         self.path_sampler = plans[path_type]()
         self.train_eps = train_eps
         self.sample_eps = sample_eps
+
+    def prior_logp(self, z):
+        """log-density of the standard normal prior, per sample (reference transport.py:69-77)."""
+        n = z[0].numel()
+        return -n / 2.0 * np.log(2 * np.pi) - z.reshape(z.shape[0], -1).pow(2).sum(1) / 2.0
 
     def check_interval(self, train_eps, sample_eps, *, diffusion_form="SBDM", sde=False, reverse=False, eval=False,
                        last_step_size=0.0):
@@ -204,5 +210,33 @@ class Sampler:
         return ode(drift=drift, t0=t0, t1=t1, sampler_type=sampling_method, num_steps=num_steps, atol=atol,
                    rtol=rtol).sample
 
-    def sample_ode_likelihood(self, *args, **kwargs):
-        raise NotImplementedError("zigma_amd: likelihood ODE needs a vjp through the forward; later scope row")
+    def sample_ode_likelihood(self, *, sampling_method="dopri5", num_steps=50, atol=1e-6, rtol=1e-3):
+        """returns fn(x, model, **model_kwargs) -> (logp, z): the data-to-noise ODE integrated together with the
+        Hutchinson estimate of the divergence (reference transport.py:419-478).  Needs a vjp through the model: with
+        `zigma_amd.model_zigma.ZigMa` that runs through the HIP backward kernels.  The reference evaluates the drift
+        twice per call (once under autograd, once for the value); one evaluation serves both here."""
+
+        def _likelihood_drift(x, t, model, **model_kwargs):
+            x, _ = x
+            eps = th.randint(2, x.size(), dtype=th.float, device=x.device).to(x.dtype) * 2 - 1
+            t = th.ones_like(t) * (1 - t)
+            with th.enable_grad():
+                x = x.detach().requires_grad_(True)
+                drift = self.drift(x, t, model, **model_kwargs)
+                grad = th.autograd.grad(th.sum(drift * eps), x)[0]
+            logp_grad = th.sum(grad * eps, dim=tuple(range(1, len(x.size()))))
+            return (-drift.detach(), logp_grad)
+
+        t0, t1 = self.transport.check_interval(self.transport.train_eps, self.transport.sample_eps, sde=False, eval=True,
+                                               reverse=False, last_step_size=0.0)
+        _ode = ode(drift=_likelihood_drift, t0=t0, t1=t1, sampler_type=sampling_method, num_steps=num_steps, atol=atol,
+                   rtol=rtol)
+
+        def _sample_fn(x, model, **model_kwargs):
+            init_logp = th.zeros(x.size(0)).to(x)
+            drift, delta_logp = _ode.sample((x, init_logp), model, **model_kwargs)
+            drift, delta_logp = drift[-1], delta_logp[-1]
+            prior_logp = self.transport.prior_logp(drift)
+            return prior_logp - delta_logp, drift
+
+        return _sample_fn
