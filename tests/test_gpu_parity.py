@@ -445,6 +445,22 @@ def test_graphed_forward_matches_eager_and_sampler_runs_on_it():
         gf(x[:1], t[:1], y[:1])
 
 
+def test_dual_stream_forward_matches_plain_forward():
+    """two half-batches on two HIP streams inside one hipGraph: same result as the plain forward (samples are
+    independent; only the library GEMMs may pick another tile for the smaller M)."""
+    from zigma_amd.graphs import DualStreamForward
+    m, g, cfg, y = _load_model("zigma_text_zigzag2")
+    x, t = T(g["x"]), T(g["t"])
+    x4, t4, y4 = torch.cat([x, x.flip(0)]), torch.cat([t, t.flip(0)]), torch.cat([y, y.flip(0)])
+    with torch.no_grad():
+        ref = m(x4, t4, y4)
+    df = DualStreamForward(m, x4, t4, y4, stagger_us=50)
+    assert rel_err(N(df(x4, t4, y4)), N(ref)) < 1e-5
+    x5 = torch.randn_like(x4)
+    with torch.no_grad():
+        assert rel_err(N(df(x5, t4, y4)), N(m(x5, t4, y4))) < 1e-5
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("L", [4096, 5000, 8192 + 16])
 def test_scan_tok_sequence_split_vs_oracle(dtype, L):
