@@ -88,6 +88,11 @@ typedef struct zigma_scan_params {
     void *x;                 /* float32 or NULL         */
     const int32_t *z_row_index;
     const int32_t *out_row_index;
+    /* optional float32 [batch][dim/64][ceil(seqlen/16)][dstate][64]: the state h BEFORE every 16-step tile, written by the
+     * token-major kernel when both out and out_z are requested (the training forward); zigma_selective_scan_bwd takes it
+     * back as `checkpoints` and skips its own forward phase.  Ignored (left untouched) by every other kernel variant:
+     * check zigma_last_kernel() == "scan_tok_n16" / "scan_tok_n8" before trusting it. */
+    float *checkpoints;
 } zigma_scan_params_t;
 
 int zigma_selective_scan_fwd(const zigma_scan_params_t *p, void *stream);
@@ -240,6 +245,8 @@ typedef struct zigma_scan_bwd_params {
      * to row z_row_index[k], and reads out / dout from row out_row_index[k].  NULL = row k. */
     const int32_t *z_row_index;
     const int32_t *out_row_index;
+    /* optional: the checkpoints the forward wrote (zigma_scan_params_t.checkpoints); NULL = recompute them here */
+    const float *checkpoints;
 } zigma_scan_bwd_params_t;
 
 int64_t zigma_selective_scan_bwd_workspace_bytes(const zigma_scan_bwd_params_t *p);

@@ -310,3 +310,26 @@ def _tiny_model():
     m = ZigMa(device=DEV, dtype=torch.float32, **cfg).eval()
     m.load_state_dict({k[3:]: torch.from_numpy(v) for k, v in g.items() if k.startswith("sd.")}, strict=True)
     return m, g, cfg, None
+
+
+@pytest.mark.parametrize("L", [100, 4096 + 32])
+def test_scan_bwd_with_forward_written_checkpoints_is_identical(L):
+    """checkpoints written by the forward kernel (single pass and the sequence-split mode) vs the backward's own phase 1."""
+    from zigma_amd import _lib
+    from zigma_amd.selective_scan_interface import scan_bwd_tok, scan_raw
+    g = torch.Generator(device="cpu").manual_seed(L)
+    Bsz, Dm, Nst = 2, 128, 16
+    r = lambda *s: torch.randn(*s, generator=g).to(DEV)
+    u, delta, z, dout = r(Bsz, L, Dm), (0.5 * torch.rand(Bsz, L, Dm, generator=g)).to(DEV), r(Bsz, L, Dm), r(Bsz, L, Dm)
+    A = (-0.5 * torch.rand(Dm, Nst, generator=g) - 0.05).to(DEV)
+    Bm, Cm, D, db = r(Bsz, L, Nst), r(Bsz, L, Nst), r(Dm), torch.rand(Dm, generator=g).to(DEV)
+    out, oz = torch.empty_like(u), torch.empty_like(u)
+    ck = torch.full((Bsz, Dm // 64, (L + 15) // 16, Nst, 64), float("nan"), device=DEV)
+    xc = torch.empty(Bsz, Dm, (L + 2047) // 2048, 2 * Nst, device=DEV) if L > 4096 else None     # lets the kernel split
+    scan_raw(u.transpose(1, 2), delta.transpose(1, 2), A, Bm.transpose(1, 2).unsqueeze(1), Cm.transpose(1, 2).unsqueeze(1), D,
+             z.transpose(1, 2), db, True, out=out.transpose(1, 2), out_z=oz.transpose(1, 2), checkpoints=ck, x=xc)
+    assert _lib.last_kernel() == "scan_tok_n16" and torch.isfinite(ck).all()
+    a = scan_bwd_tok(u, delta, A, Bm, Cm, D, z, db, dout, out, True, checkpoints=ck)
+    b = scan_bwd_tok(u, delta, A, Bm, Cm, D, z, db, dout, out, True)
+    for x, y in zip(a, b):
+        assert torch.equal(x, y) if L <= 4096 else rel_err(N(x), N(y)) < 1e-5      # split mode: carries combine in another order

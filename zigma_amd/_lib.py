@@ -34,7 +34,7 @@ class ScanParams(C.Structure):
             "B_batch_stride", "B_group_stride", "B_d_stride", "B_dstate_stride", "B_l_stride",
             "C_batch_stride", "C_group_stride", "C_d_stride", "C_dstate_stride", "C_l_stride")]
         + [(n, vp) for n in ("u", "delta", "A", "B", "C", "D", "delta_bias", "z", "out", "out_z", "x",
-                             "z_row_index", "out_row_index")]
+                             "z_row_index", "out_row_index", "checkpoints")]
     )
 
 
@@ -75,7 +75,7 @@ class ScanBwdParams(C.Structure):
                     "dB_l_stride", "dC_batch_stride", "dC_dstate_stride", "dC_l_stride")]
                 + [(n, vp) for n in ("u", "delta", "A", "B", "C", "D", "delta_bias", "z", "out", "dout", "du", "ddelta",
                                      "dz", "dA", "dB", "dC", "dD", "ddelta_bias", "workspace")]
-                + [("workspace_bytes", i64), ("z_row_index", vp), ("out_row_index", vp)])
+                + [("workspace_bytes", i64), ("z_row_index", vp), ("out_row_index", vp), ("checkpoints", vp)])
 
 
 class ConvBwdParams(C.Structure):

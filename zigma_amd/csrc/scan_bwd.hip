@@ -87,7 +87,7 @@ __global__ __launch_bounds__(64 * NW, 2) void scan_bwd_kernel(const zigma_scan_b
         const int k = clampk(t * LT + g * 4 + bc_s);
         return to_float<IO>(buf_ld<IO>(rs, lane_base + static_cast<unsigned>(k * ls), 0));
     };
-    float *ck = ws.ck + (static_cast<int64_t>(b) * n_slabs + slab) * n_tiles * N * 64;
+    float *ck = (p.checkpoints ? const_cast<float *>(p.checkpoints) : ws.ck) + (static_cast<int64_t>(b) * n_slabs + slab) * n_tiles * N * 64;
 
 #define ZIGMA_BC(Bf, S, J) row_bcast<(S) * 4 + (J)>(Bf)
 
@@ -110,9 +110,10 @@ __global__ __launch_bounds__(64 * NW, 2) void scan_bwd_kernel(const zigma_scan_b
 #pragma unroll
         for (int g = 0; g < NG; ++g) pb[g] = bc_raw(B_rs, B_lane, B_ls, t, g);
     };
-    fetch_fwd(0);
+    const bool own_ck = p.checkpoints == nullptr;      // else: the forward kernel already wrote them
+    if (own_ck) fetch_fwd(0);
 #pragma unroll 1
-    for (int t = 0; t < n_tiles; ++t) {
+    for (int t = 0; t < (own_ck ? n_tiles : 0); ++t) {
 #pragma unroll
         for (int i = 0; i < RPT; ++i) {
             const int row = wave * RPT + i, k = t * LT + row;
@@ -386,7 +387,7 @@ __global__ void scan_bwd_finish_params(const zigma_scan_bwd_params_t p, const Bw
 
 static void bwd_ws_layout(const zigma_scan_bwd_params_t &p, int64_t &ck, int64_t &bc, int64_t &pa) {
     const int64_t n_tiles = (p.seqlen + kBT - 1) / kBT, slabs = p.dim / 64;
-    ck = static_cast<int64_t>(p.batch) * slabs * n_tiles * p.dstate * 64;
+    ck = p.checkpoints ? 0 : static_cast<int64_t>(p.batch) * slabs * n_tiles * p.dstate * 64;
     bc = static_cast<int64_t>(p.batch) * slabs * n_tiles * kBT * 2 * p.dstate;
     pa = static_cast<int64_t>(p.batch) * p.dim * (p.dstate + 2);
 }

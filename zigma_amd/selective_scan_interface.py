@@ -33,7 +33,7 @@ def _as_bgnl(M, name):
 
 
 def scan_raw(u, delta, A, B, C, D=None, z=None, delta_bias=None, delta_softplus=False, *, out=None, out_z=None,
-             x=None, z_row_index=None, out_row_index=None, want_out=True):
+             x=None, z_row_index=None, out_row_index=None, want_out=True, checkpoints=None):
     """Launch zigma_selective_scan_fwd.  All tensors are logical (batch, dim, seqlen) VIEWS with arbitrary
     strides (token-major tensors come in as `.transpose(1, 2)`); B/C are (D, N) f32 or (B, G, N, L) views.
     Outputs that are None are allocated here with the reference's conventions (out like delta, out_z like z)."""
@@ -126,6 +126,10 @@ def scan_raw(u, delta, A, B, C, D=None, z=None, delta_bias=None, delta_softplus=
             if idx.dtype != torch.int32 or idx.shape != (L,) or not idx.is_contiguous():
                 raise RuntimeError(f"{name} must be a contiguous int32 tensor of length seqlen")
             setattr(P, name, _lib.ptr(idx))
+    if checkpoints is not None:
+        if checkpoints.dtype != torch.float32 or not checkpoints.is_contiguous():
+            raise RuntimeError("checkpoints must be a contiguous float32 buffer")
+        P.checkpoints = _lib.ptr(checkpoints)
     _lib.call("zigma_selective_scan_fwd", P, dev)
     return out, out_z
 
@@ -164,7 +168,7 @@ def dt_proj_softplus(x_dbl, dt_rank, weight, bias=None, softplus=True):
 
 
 def scan_bwd_tok(u, delta, A, B, C, D, z, delta_bias, dout, out, delta_softplus, *, dB=None, dC=None, dz=None,
-                 z_row_index=None, out_row_index=None):
+                 z_row_index=None, out_row_index=None, checkpoints=None):
     """Backward of the token-major selective scan (zigma_selective_scan_bwd; reference selective_scan_cuda.bwd,
     selective_scan.cpp:338-492).
 
@@ -223,6 +227,11 @@ def scan_bwd_tok(u, delta, A, B, C, D, z, delta_bias, dout, out, delta_softplus,
             if tab.dtype != torch.int32 or tab.shape != (L,) or not tab.is_contiguous():
                 raise RuntimeError(f"{name} must be a contiguous int32 (seqlen,) table")
             setattr(P, name, _lib.ptr(tab))
+    if checkpoints is not None:            # written by the forward kernel (scan_raw(..., checkpoints=)): skip phase 1
+        if checkpoints.dtype != torch.float32 or not checkpoints.is_contiguous() or \
+                checkpoints.numel() != Bsz * (Dm // 64) * ((L + 15) // 16) * N * 64:
+            raise RuntimeError("checkpoints: float32 [batch][dim/64][ceil(seqlen/16)][dstate][64]")
+        P.checkpoints = _lib.ptr(checkpoints)
     ws = _lib.workspace("zigma_selective_scan_bwd", P, dev)
     _lib.call("zigma_selective_scan_bwd", P, dev)
     del ws
@@ -249,11 +258,18 @@ class MambaInnerTokFn(torch.autograd.Function):
         Bm, Cm = x_dbl[:, :, R:R + N], x_dbl[:, :, R + N:R + 2 * N]
         out = torch.empty(Bsz, L, Di, device=xz.device, dtype=xz.dtype)
         y = torch.empty(Bsz, L, Di, device=xz.device, dtype=xz.dtype)
+        # the states before every 16-step tile, for the backward's reverse sweep (the token-major kernel writes them on
+        # its way: 4 * Di * N * L / 16 bytes per sample; anything else leaves the buffer alone and the backward recomputes)
+        ck = None
+        if Di % 64 == 0 and N in (8, 16):
+            ck = torch.empty(Bsz, Di // 64, (L + 15) // 16, N, 64, device=xz.device, dtype=torch.float32)
         scan_raw(u.transpose(1, 2), delta.transpose(1, 2), A, Bm.transpose(1, 2).unsqueeze(1),
                  Cm.transpose(1, 2).unsqueeze(1), D, z_half.transpose(1, 2), delta_bias, True,
-                 out=out.transpose(1, 2), out_z=y.transpose(1, 2), z_row_index=perm, out_row_index=out_rows)
+                 out=out.transpose(1, 2), out_z=y.transpose(1, 2), z_row_index=perm, out_row_index=out_rows, checkpoints=ck)
+        if ck is not None and not _lib.last_kernel().startswith("scan_tok"):
+            ck = None
         ctx.save_for_backward(xz, conv_w, conv_b, x_proj_w, dt_proj_w, A, D, delta_bias, u, x_dbl, delta, out)
-        ctx.perm, ctx.out_rows = perm, out_rows
+        ctx.perm, ctx.out_rows, ctx.ck = perm, out_rows, ck
         return y
 
     @staticmethod
@@ -268,7 +284,8 @@ class MambaInnerTokFn(torch.autograd.Function):
         du, ddelta, dA, _, _, dD, _, dbias = scan_bwd_tok(
             u, delta, A, x_dbl[:, :, R:R + N], x_dbl[:, :, R + N:R + 2 * N], D, z_half, delta_bias, dy, out, True,
             dB=dx_dbl[:, :, R:R + N], dC=dx_dbl[:, :, R + N:], dz=dxz[:, :, Di:], z_row_index=ctx.perm,
-            out_row_index=ctx.out_rows)
+            out_row_index=ctx.out_rows, checkpoints=ctx.ck)
+        ctx.ck = None
         dd2 = ddelta.reshape(-1, Di)
         dx_dbl[:, :, :R] = (dd2 @ dt_proj_w).reshape(Bsz, L, R)                  # d(x_dbl[:, :R]) = ddelta @ W_dt
         d_dt_w = dd2.t() @ x_dbl.reshape(-1, R + 2 * N)[:, :R]                     # (Di, R)
