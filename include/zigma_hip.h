@@ -316,6 +316,28 @@ typedef struct zigma_norm_bwd_params {
 int64_t zigma_add_norm_bwd_workspace_bytes(const zigma_norm_bwd_params_t *p);
 int zigma_add_norm_bwd(const zigma_norm_bwd_params_t *p, void *stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Cross-attention core over a short context:  out = softmax(scale * Q K^T) V  per (sample, head), no mask.
+ * Replaces the scaled_dot_product_attention / xformers call of CrossAttention.forward (reference model_zigma.py:113-127;
+ * ZigMa: 8 heads x 64, 77 text tokens).  q, out: (batch, seqlen, heads*head_dim) rows; k, v: (batch, n_ctx, heads*head_dim)
+ * rows (any row / batch pitch: e.g. slices of one batched K/V projection); head h = columns [h*head_dim, (h+1)*head_dim).
+ * Limits: bf16, head_dim 64, n_ctx <= 128, rows 16-byte aligned.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct zigma_xattn_params {
+    int32_t batch, seqlen, n_ctx, heads, head_dim;
+    int32_t dtype;
+    int32_t flags;   /* reserved, must be 0 */
+    float scale;     /* head_dim^-0.5 in the reference */
+    int64_t q_batch_stride, q_row_stride;
+    int64_t k_batch_stride, k_row_stride;
+    int64_t v_batch_stride, v_row_stride;
+    int64_t o_batch_stride, o_row_stride;
+    const void *q, *k, *v;
+    void *out;
+} zigma_xattn_params_t;
+
+int zigma_cross_attn_fwd(const zigma_xattn_params_t *p, void *stream);
+
 /* ------------------------------------------------------------------------------------------ */
 const char *zigma_strerror(int status);
 int zigma_abi_version(void);

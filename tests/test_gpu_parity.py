@@ -445,6 +445,31 @@ def test_graphed_forward_matches_eager_and_sampler_runs_on_it():
         gf(x[:1], t[:1], y[:1])
 
 
+@pytest.mark.parametrize("Bsz,L,H,NC", [(2, 100, 8, 77), (1, 64, 3, 128), (3, 17, 8, 5), (2, 256, 8, 81)])
+def test_cross_attn_kernel_vs_oracle(Bsz, L, H, NC):
+    """softmax(scale Q K^T) V per head on the matrix cores vs a float64 numpy evaluation on the same bf16 operands; K / V
+    are row-strided slices of one buffer, as the batched K/V projection hands them over."""
+    from zigma_amd import _lib
+    from zigma_amd.attention import cross_attn, cross_attn_eligible
+    rng = np.random.default_rng(L + NC)
+    C = H * 64
+    q = zo.bf16_round(rng.standard_normal((Bsz, L, C)).astype(np.float32))
+    kv = zo.bf16_round(rng.standard_normal((Bsz, NC, 2, C)).astype(np.float32))
+    kvt = T(kv, torch.bfloat16)
+    k, v = kvt[:, :, 0], kvt[:, :, 1]
+    assert cross_attn_eligible(T(q, torch.bfloat16), k, v, H)
+    out = cross_attn(T(q, torch.bfloat16), k, v, H)
+    assert _lib.last_kernel() == "cross_attn_mfma" and out.shape == (Bsz, L, C)
+    qh = q.reshape(Bsz, L, H, 64).transpose(0, 2, 1, 3).astype(np.float64)
+    kh = kv[:, :, 0].reshape(Bsz, NC, H, 64).transpose(0, 2, 1, 3).astype(np.float64)
+    vh = kv[:, :, 1].reshape(Bsz, NC, H, 64).transpose(0, 2, 1, 3).astype(np.float64)
+    sc = qh @ kh.transpose(0, 1, 3, 2) * 64 ** -0.5
+    pr = np.exp(sc - sc.max(-1, keepdims=True))
+    ref = ((pr / pr.sum(-1, keepdims=True)) @ vh).transpose(0, 2, 1, 3).reshape(Bsz, L, C)
+    assert rel_err(N(out), ref) < 6e-3            # P is rounded to bf16 for the second MFMA, the output to bf16
+    assert np.allclose(N(out), ref, rtol=3e-2, atol=3e-2)
+
+
 def test_dual_stream_forward_matches_plain_forward():
     """two half-batches on two HIP streams inside one hipGraph: same result as the plain forward (samples are
     independent; only the library GEMMs may pick another tile for the smaller M)."""

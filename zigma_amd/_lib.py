@@ -96,7 +96,14 @@ class NormBwdParams(C.Structure):
                 + [("workspace_bytes", i64)])
 
 
-EXPORTS = ("zigma_selective_scan_fwd", "zigma_causal_conv1d_fwd", "zigma_add_norm_fwd", "zigma_dt_proj_softplus_fwd", "zigma_selective_scan_bwd",
+class XAttnParams(C.Structure):
+    _fields_ = ([(n, i32) for n in ("batch", "seqlen", "n_ctx", "heads", "head_dim", "dtype", "flags")] + [("scale", f32)]
+                + [(n, i64) for n in ("q_batch_stride", "q_row_stride", "k_batch_stride", "k_row_stride", "v_batch_stride",
+                                      "v_row_stride", "o_batch_stride", "o_row_stride")]
+                + [(n, vp) for n in ("q", "k", "v", "out")])
+
+
+EXPORTS = ("zigma_selective_scan_fwd", "zigma_causal_conv1d_fwd", "zigma_add_norm_fwd", "zigma_dt_proj_softplus_fwd", "zigma_cross_attn_fwd", "zigma_selective_scan_bwd",
            "zigma_selective_scan_bwd_workspace_bytes", "zigma_causal_conv1d_bwd",
            "zigma_causal_conv1d_bwd_workspace_bytes", "zigma_add_norm_bwd", "zigma_add_norm_bwd_workspace_bytes",
            "zigma_strerror",
@@ -117,7 +124,7 @@ def lib():
         for name, st in (("zigma_selective_scan_fwd", ScanParams), ("zigma_causal_conv1d_fwd", ConvParams),
                          ("zigma_add_norm_fwd", NormParams), ("zigma_dt_proj_softplus_fwd", DtProjParams),
                          ("zigma_selective_scan_bwd", ScanBwdParams), ("zigma_causal_conv1d_bwd", ConvBwdParams),
-                         ("zigma_add_norm_bwd", NormBwdParams)):
+                         ("zigma_add_norm_bwd", NormBwdParams), ("zigma_cross_attn_fwd", XAttnParams)):
             fn = getattr(L, name)
             fn.argtypes = [C.POINTER(st), vp]
             fn.restype = C.c_int

@@ -27,6 +27,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 from torch import Tensor
 
+from .attention import cross_attn, cross_attn_eligible
 from .layernorm import RMSNorm, block_norm, layer_norm_fn, rms_norm_fn
 from .mamba_simple import Mamba
 from .scan_paths import hilbert_path, reverse_permut_np, zigzag_path
@@ -79,8 +80,11 @@ class CrossAttention(nn.Module):
         projections of all layers into one GEMM since `text` is the same for every block."""
         Bsz, L, _ = x.shape
         H = self.heads
-        q = self.to_q(x).view(Bsz, L, H, -1).transpose(1, 2)
+        q = self.to_q(x)
         k, v = kv if kv is not None else (self.to_k(text), self.to_v(text))
+        if not torch.is_grad_enabled() and cross_attn_eligible(q, k, v, H):
+            return self.to_out(cross_attn(q, k, v, H, self.scale))      # HIP kernel: one pass, K/V of the head in LDS
+        q = q.view(Bsz, L, H, -1).transpose(1, 2)
         k = k.reshape(Bsz, k.shape[1], H, -1).transpose(1, 2)
         v = v.reshape(Bsz, v.shape[1], H, -1).transpose(1, 2)
         o = F.scaled_dot_product_attention(q, k, v)
