@@ -12,7 +12,7 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libzigma_hip.so")
+LIB_PATH = os.environ.get("ZIGMA_AMD_LIB") or os.path.join(_HERE, "lib", "libzigma_hip.so")   # env: A/B builds in tools/
 
 F32, F16, BF16 = 0, 1, 2
 _DT = {torch.float32: F32, torch.float16: F16, torch.bfloat16: BF16}
