@@ -93,6 +93,11 @@ typedef struct zigma_scan_params {
      * back as `checkpoints` and skips its own forward phase.  Ignored (left untouched) by every other kernel variant:
      * check zigma_last_kernel() == "scan_tok_n16" / "scan_tok_n8" before trusting it. */
     float *checkpoints;
+    /* > 0: the sequence is a concatenation of independent sequences of this many steps (a multiple of 16): the state is
+     * reset to 0 at every multiple.  Lets the video temporal layers (b (t k) c tokens, scan over t for every (b, k)) run as
+     * batch = k, seqlen = b * t on strided views with no transposing copy.  Token-major kernel only; x must be NULL. */
+    int32_t reset_period;
+    int32_t pad2_;
 } zigma_scan_params_t;
 
 int zigma_selective_scan_fwd(const zigma_scan_params_t *p, void *stream);
@@ -122,6 +127,10 @@ typedef struct zigma_conv_params {
     const void *bias;  /* or NULL */
     void *out;
     const int32_t *x_row_index;
+    /* > 0: independent sequences of this many positions (a multiple of 16) concatenated along seqlen: the causal window
+     * does not reach across a multiple (zero padding restarts there).  Token-major kernel only. */
+    int32_t reset_period;
+    int32_t pad2_;
 } zigma_conv_params_t;
 
 int zigma_causal_conv1d_fwd(const zigma_conv_params_t *p, void *stream);

@@ -11,7 +11,8 @@ def _np(t):
     return None if t is None else t.detach().float().cpu().numpy()
 
 
-def conv_raw(x, weight, bias, silu, *, out=None, x_row_index=None):
+def conv_raw(x, weight, bias, silu, *, out=None, x_row_index=None, reset_period=0):
+    assert not reset_period, "stand-in: reset_period is exercised on the GPU only"
     xs = _np(x)
     if x_row_index is not None:
         xs = xs[:, :, x_row_index.long().cpu().numpy()]
@@ -24,7 +25,8 @@ def conv_raw(x, weight, bias, silu, *, out=None, x_row_index=None):
 
 
 def scan_raw(u, delta, A, B, C, D=None, z=None, delta_bias=None, delta_softplus=False, *, out=None, out_z=None,
-             x=None, z_row_index=None, out_row_index=None, want_out=True):
+             x=None, z_row_index=None, out_row_index=None, want_out=True, checkpoints=None, reset_period=0):
+    assert not reset_period and checkpoints is None, "stand-in: GPU-only features"
     zs = _np(z)
     if zs is not None and z_row_index is not None:
         zs = zs[:, :, z_row_index.long().cpu().numpy()]

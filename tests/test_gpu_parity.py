@@ -509,3 +509,28 @@ def test_scan_tok_sequence_split_vs_oracle(dtype, L):
     c2["has_z"] = False
     _, last2048 = _oracle_tok(c2, dtype)
     assert rel_err(N(x[:, :, 0, 1::2]), last2048) < 2e-5
+
+
+def test_reset_period_matches_separate_sequences():
+    """conv + scan with reset_period (independent sequences concatenated along seqlen, read through strided views) vs the
+    same sequences run as separate batch rows: the no-copy path of the video temporal layers."""
+    from zigma_amd.selective_scan_interface import mamba_inner_tok
+    g = torch.Generator(device="cpu").manual_seed(2)
+    Bsz, T, K, Di, R, Nst = 3, 16, 8, 128, 8, 16
+    mk = lambda *s, sc=1.0: (torch.randn(*s, generator=g) * sc).to(DEV)
+    xz = mk(Bsz, T * K, 2 * Di)                                   # tokens (b, t, k)
+    cw, cb, xw, dw = mk(Di, 1, 4, sc=0.5), mk(Di, sc=0.1), mk(R + 2 * Nst, Di, sc=Di ** -0.5), mk(Di, R, sc=R ** -0.5)
+    A, D, db = -torch.exp(mk(Di, Nst, sc=0.5)), mk(Di), torch.rand(Di, generator=g).to(DEV)
+    perm_t = torch.randperm(T, generator=g).to(DEV, torch.int32)
+    out_t = torch.randperm(T, generator=g).to(DEV, torch.int32)
+    with torch.no_grad():
+        # reference arrangement: (b k) t c with one transposing copy in and one out
+        xt = xz.view(Bsz, T, K, 2 * Di).transpose(1, 2).reshape(Bsz * K, T, 2 * Di)
+        yt = mamba_inner_tok(xt, cw, cb, xw, dw, A, D, db, perm=perm_t, out_rows=out_t)
+        ref = yt.view(Bsz, K, T, Di).transpose(1, 2).reshape(Bsz, T * K, Di)
+        # no-copy arrangement
+        base = (torch.arange(Bsz, device=DEV, dtype=torch.int32) * T).repeat_interleave(T)
+        y = torch.empty(Bsz, T * K, Di, device=DEV)
+        mamba_inner_tok(xz.view(Bsz * T, K, 2 * Di).transpose(0, 1), cw, cb, xw, dw, A, D, db, perm=base + perm_t.repeat(Bsz),
+                        out_rows=base + out_t.repeat(Bsz), reset_period=T, out=y.view(Bsz * T, K, Di).transpose(0, 1))
+    assert rel_err(N(y), N(ref)) < 1e-6

@@ -35,6 +35,7 @@ class ScanParams(C.Structure):
             "C_batch_stride", "C_group_stride", "C_d_stride", "C_dstate_stride", "C_l_stride")]
         + [(n, vp) for n in ("u", "delta", "A", "B", "C", "D", "delta_bias", "z", "out", "out_z", "x",
                              "z_row_index", "out_row_index", "checkpoints")]
+        + [("reset_period", i32), ("pad2_", i32)]
     )
 
 
@@ -44,6 +45,7 @@ class ConvParams(C.Structure):
         + [(n, i64) for n in ("x_batch_stride", "x_c_stride", "x_l_stride", "weight_c_stride", "weight_width_stride",
                               "out_batch_stride", "out_c_stride", "out_l_stride")]
         + [(n, vp) for n in ("x", "weight", "bias", "out", "x_row_index")]
+        + [("reset_period", i32), ("pad2_", i32)]
     )
 
 

@@ -10,7 +10,7 @@ import torch
 from . import _lib
 
 
-def causal_conv1d_raw(x, weight, bias, silu, *, out=None, x_row_index=None):
+def causal_conv1d_raw(x, weight, bias, silu, *, out=None, x_row_index=None, reset_period=0):
     """x, out: logical (batch, dim, seqlen) views, any strides.  weight (dim, width), bias (dim,) or None."""
     dev = _lib.require_device(x, weight, bias, out, x_row_index)
     if x.dim() != 3:
@@ -42,6 +42,7 @@ def causal_conv1d_raw(x, weight, bias, silu, *, out=None, x_row_index=None):
         if x_row_index.dtype != torch.int32 or x_row_index.shape != (L,) or not x_row_index.is_contiguous():
             raise RuntimeError("x_row_index must be a contiguous int32 tensor of length seqlen")
         P.x_row_index = _lib.ptr(x_row_index)
+    P.reset_period = int(reset_period)       # > 0: independent sequences of that many positions along seqlen
     _lib.call("zigma_causal_conv1d_fwd", P, dev)
     return out
 

@@ -54,13 +54,15 @@ __global__ __launch_bounds__(64) void conv_tok_kernel(const zigma_conv_params_t 
         k = k < 0 ? 0 : (k < L ? k : L - 1);
         rowv = p.x_row_index ? p.x_row_index[k] : k;
     }
+    // first position the causal window may reach: 0, or the start of this tile's own sequence (LT divides reset_period)
+    const int k_lo = p.reset_period > 0 ? (k0 / p.reset_period) * p.reset_period : 0;
     P raw[NR];
 #pragma unroll
     for (int i = 0; i < NR; ++i) {
         const int k = k0 - (W - 1) + i;                       // wave-uniform
         const int row = __builtin_amdgcn_readlane(rowv, i);
         raw[i] = P{};
-        if (k >= 0 && k < L) raw[i] = buf_ld4<IO>(x_rs, lane_off, row * x_ls);   // zero left padding otherwise
+        if (k >= k_lo && k < L) raw[i] = buf_ld4<IO>(x_rs, lane_off, row * x_ls);   // zero left padding otherwise
     }
 #pragma unroll
     for (int j = 0; j < LT; ++j) {
@@ -117,6 +119,8 @@ static int launch_conv(const zigma_conv_params_t &p, hipStream_t stream) {
                      p.x_l_stride >= 0 && p.out_l_stride >= 0 &&
                      (p.x_l_stride * p.seqlen + p.dim) * static_cast<int64_t>(es) < (int64_t(1) << 31) &&
                      (p.out_l_stride * p.seqlen + p.dim) * static_cast<int64_t>(es) < (int64_t(1) << 31);
+    if (p.reset_period < 0 || p.reset_period % 16 != 0) return ZIGMA_ERR_SHAPE;
+    if (p.reset_period > 0 && !tok) return ZIGMA_ERR_STRIDE;   // only the token-major kernel restarts sequences
     if (tok) {
         constexpr int LT = 16;
         dim3 grid((p.dim / 4 + 63) / 64, (p.seqlen + LT - 1) / LT, p.batch), block(64);

@@ -187,6 +187,8 @@ extern "C" int zigma_selective_scan_fwd(const zigma_scan_params_t *pp, void *str
     if (p.z && !p.out_z) return ZIGMA_ERR_NULL;
     if (!p.z && !p.out) return ZIGMA_ERR_NULL;
 
+    if (p.reset_period < 0 || p.reset_period % 16 != 0 || (p.reset_period > 0 && p.x)) return ZIGMA_ERR_SHAPE;
+    if (p.reset_period > 0 && !tok_eligible(p)) return ZIGMA_ERR_STRIDE;   // only the token-major kernel restarts sequences
     if (tok_eligible(p)) {
         switch (p.io_dtype) {
             case ZIGMA_BF16: return launch_scan_tok_bf16(p, stream);

@@ -118,6 +118,7 @@ class Mamba(nn.Module):
         self.register_buffer("_out_rows", out_rows, persistent=False)
         self._rev_cache = {}
         self._const_cache = {}
+        self._tile_cache = {}
 
     def _s4d_real_log(self, device):
         A = torch.arange(1, self.d_state + 1, dtype=torch.float32, device=device).repeat(self.d_inner, 1).contiguous()
@@ -157,6 +158,17 @@ class Mamba(nn.Module):
             self._const_cache[sfx] = hit
         return hit[1]
 
+    def _tiled_tables(self, batch, T):
+        """(gather, write-back) time tables of length batch * T: entry b * T + t = b * T + table[t]."""
+        key = (batch, T, str(self._perm.device))
+        hit = self._tile_cache.get(key)
+        if hit is None:
+            base = (torch.arange(batch, device=self._perm.device, dtype=torch.int32) * T).repeat_interleave(T)
+            out_rows = self._out_rows if self._out_rows is not None else self._perm
+            hit = ((base + self._perm.repeat(batch)).contiguous(), (base + out_rows.repeat(batch)).contiguous())
+            self._tile_cache[key] = hit
+        return hit
+
     def _reversed_table(self, L, device):
         key = (L, str(device))
         if key not in self._rev_cache:
@@ -195,6 +207,15 @@ class Mamba(nn.Module):
             s_or_t = self.st_order[self.layer_idx]
             if s_or_t == "s":       # b (t k) c -> (b t) k c : a pure view
                 y = fwd(xz.view(batch * T, K, C2), self._perm).view(batch, seqlen, -1)
+            elif s_or_t == "t" and not torch.is_grad_enabled() and T % 16 == 0 and xz.numel() < 2 ** 29:
+                # b (t k) c -> scan over t for every (b, k) WITHOUT the two transposing copies: batch = k, sequence =
+                # (b, t) with stride K rows, conv window and SSM state restart every T steps (reset_period); the time
+                # tables are tiled over b.  Strided views in, strided view out.
+                perm_bt, out_bt = self._tiled_tables(batch, T)
+                y = torch.empty(batch, seqlen, C2 // 2, device=xz.device, dtype=xz.dtype)
+                mamba_inner_tok(xz.view(batch * T, K, C2).transpose(0, 1), self.conv1d.weight, self.conv1d.bias,
+                                self.x_proj.weight, self.dt_proj.weight, A, Dp, dtb, perm=perm_bt, out_rows=out_bt,
+                                delta_softplus=True, reset_period=T, out=y.view(batch * T, K, C2 // 2).transpose(0, 1))
             elif s_or_t == "t":     # b (t k) c -> (b k) t c : one transposing copy in, one out
                 xt = xz.view(batch, T, K, C2).transpose(1, 2).reshape(batch * K, T, C2)
                 yt = fwd(xt, self._perm)

@@ -33,7 +33,7 @@ def _as_bgnl(M, name):
 
 
 def scan_raw(u, delta, A, B, C, D=None, z=None, delta_bias=None, delta_softplus=False, *, out=None, out_z=None,
-             x=None, z_row_index=None, out_row_index=None, want_out=True, checkpoints=None):
+             x=None, z_row_index=None, out_row_index=None, want_out=True, checkpoints=None, reset_period=0):
     """Launch zigma_selective_scan_fwd.  All tensors are logical (batch, dim, seqlen) VIEWS with arbitrary
     strides (token-major tensors come in as `.transpose(1, 2)`); B/C are (D, N) f32 or (B, G, N, L) views.
     Outputs that are None are allocated here with the reference's conventions (out like delta, out_z like z)."""
@@ -130,6 +130,7 @@ def scan_raw(u, delta, A, B, C, D=None, z=None, delta_bias=None, delta_softplus=
         if checkpoints.dtype != torch.float32 or not checkpoints.is_contiguous():
             raise RuntimeError("checkpoints must be a contiguous float32 buffer")
         P.checkpoints = _lib.ptr(checkpoints)
+    P.reset_period = int(reset_period)       # > 0: independent sequences of that many steps along seqlen
     _lib.call("zigma_selective_scan_fwd", P, dev)
     return out, out_z
 
@@ -357,7 +358,8 @@ def mamba_inner_fn_no_out_proj(xz, conv1d_weight, conv1d_bias, x_proj_weight, de
 
 
 def mamba_inner_tok(xz, conv1d_weight, conv1d_bias, x_proj_weight, delta_proj_weight, A, D, delta_bias, *,
-                    perm=None, out_rows=None, B_proj_bias=None, C_proj_bias=None, delta_softplus=True, out=None):
+                    perm=None, out_rows=None, B_proj_bias=None, C_proj_bias=None, delta_softplus=True, out=None,
+                    reset_period=0):
     """Token-major Mamba inner (no out_proj).
 
     xz: (batch, seqlen, 2*d_inner), token order, channel contiguous (the in_proj GEMM output as is).
@@ -368,14 +370,17 @@ def mamba_inner_tok(xz, conv1d_weight, conv1d_bias, x_proj_weight, delta_proj_we
           out[out_rows[k]] = out'[k] (defaults to perm).  The reference pairs its temporal table [0..T-1] with
           the "reverse" table [T-1..0] (model_zigma.py:765-772), i.e. out = out'[:, perm_rev] with perm_rev not
           the inverse of perm; the caller passes out_rows = inverse(perm_rev) to reproduce exactly that.
+    reset_period: > 0 = every batch row is a concatenation of independent sequences of that many steps (multiple of 16):
+          conv window and SSM state restart there (the video temporal layers: batch = k, seqlen = b * t on strided views).
+          Forward only.
     Returns y (batch, seqlen, d_inner) in token order = out_z of the reference's scan, before out_proj.
     """
     if xz.dim() != 3 or xz.stride(2) != 1:
         raise RuntimeError("xz must be (batch, seqlen, 2*d_inner) with contiguous channels")
     if torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in (
             xz, conv1d_weight, conv1d_bias, x_proj_weight, delta_proj_weight, A, D, delta_bias)):
-        if B_proj_bias is not None or C_proj_bias is not None or not delta_softplus or out is not None:
-            raise NotImplementedError("differentiable mamba_inner_tok: no B/C projection bias, softplus on, no out=")
+        if B_proj_bias is not None or C_proj_bias is not None or not delta_softplus or out is not None or reset_period:
+            raise NotImplementedError("differentiable mamba_inner_tok: no B/C projection bias, softplus on, no out=, no reset_period")
         return mamba_inner_tok_train(xz, conv1d_weight, conv1d_bias, x_proj_weight, delta_proj_weight, A, D, delta_bias,
                                      perm=perm, out_rows=out_rows)
     Bsz, L, C2 = xz.shape
@@ -386,7 +391,8 @@ def mamba_inner_tok(xz, conv1d_weight, conv1d_bias, x_proj_weight, delta_proj_we
     x_half, z_half = xz[:, :, :Di], xz[:, :, Di:]
     # depthwise causal conv + SiLU over the reordered sequence; u is in SCAN order
     u = torch.empty(Bsz, L, Di, device=xz.device, dtype=xz.dtype)
-    causal_conv1d_raw(x_half.transpose(1, 2), w, conv1d_bias, True, out=u.transpose(1, 2), x_row_index=perm)
+    causal_conv1d_raw(x_half.transpose(1, 2), w, conv1d_bias, True, out=u.transpose(1, 2), x_row_index=perm,
+                      reset_period=reset_period)
     x_dbl = F.linear(u, x_proj_weight)                               # (B, L, R + 2N)   GEMM
     fused_dt = delta_softplus and dt_proj_eligible(x_dbl, R, delta_proj_weight)
     if fused_dt:   # K = dt_rank GEMM + bias + softplus in one write-bound MFMA kernel; scan skips its softplus
@@ -407,5 +413,5 @@ def mamba_inner_tok(xz, conv1d_weight, conv1d_bias, x_proj_weight, delta_proj_we
     scan_raw(u.transpose(1, 2), delta.transpose(1, 2), A, Bm.transpose(1, 2).unsqueeze(1),
              Cm.transpose(1, 2).unsqueeze(1), D, z_half.transpose(1, 2), delta_bias, delta_softplus,
              out_z=y.transpose(1, 2), z_row_index=perm, out_row_index=perm if out_rows is None else out_rows,
-             want_out=False, x=xc)
+             want_out=False, x=xc, reset_period=reset_period)
     return y
