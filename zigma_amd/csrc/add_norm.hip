@@ -41,6 +41,41 @@ template <typename T> __device__ __forceinline__ void store4(void *base, int64_t
                        from_float<T>(f[2]) | (uint32_t(from_float<T>(f[3])) << 16));
     }
 }
+// VEC consecutive elements: 1 (scalar), 4, or 8 (two float4 / one 16-byte piece of 16-bit elements)
+template <typename T, int VEC> __device__ __forceinline__ void loadv(const void *base, int64_t idx, float (&f)[VEC]) {
+    if constexpr (VEC == 1) {
+        f[0] = ld<T>(base, idx);
+    } else if constexpr (VEC == 4) {
+        load4<T>(base, idx, f);
+    } else if constexpr (T::id == ZIGMA_F32) {
+        float a[4], b[4];
+        load4<T>(base, idx, a);
+        load4<T>(base, idx + 4, b);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { f[i] = a[i]; f[4 + i] = b[i]; }
+    } else {
+        const uint4 r = *reinterpret_cast<const uint4 *>(reinterpret_cast<const uint16_t *>(base) + idx);
+        const uint32_t w[4] = {r.x, r.y, r.z, r.w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { f[2 * i] = to_float<T>(w[i] & 0xffffu); f[2 * i + 1] = to_float<T>(w[i] >> 16); }
+    }
+}
+template <typename T, int VEC> __device__ __forceinline__ void storev(void *base, int64_t idx, const float (&f)[VEC]) {
+    if constexpr (VEC == 1) {
+        st<T>(base, idx, f[0]);
+    } else if constexpr (VEC == 4) {
+        store4<T>(base, idx, f);
+    } else if constexpr (T::id == ZIGMA_F32) {
+        const float a[4] = {f[0], f[1], f[2], f[3]}, b[4] = {f[4], f[5], f[6], f[7]};
+        store4<T>(base, idx, a);
+        store4<T>(base, idx + 4, b);
+    } else {
+        uint32_t w[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) w[i] = from_float<T>(f[2 * i]) | (uint32_t(from_float<T>(f[2 * i + 1])) << 16);
+        *reinterpret_cast<uint4 *>(reinterpret_cast<uint16_t *>(base) + idx) = make_uint4(w[0], w[1], w[2], w[3]);
+    }
+}
 // value the tensor would hold after being stored in dtype T (the reference materialises these tensors)
 template <typename T> __device__ __forceinline__ float rnd(float v) { return to_float<T>(from_float<T>(v)); }
 
@@ -60,29 +95,25 @@ __global__ __launch_bounds__(256) void add_norm_kernel(const zigma_norm_params_t
         const int c = (it * 64 + lane) * VEC;
         if (c < cols) {
             float x[VEC];
-            if constexpr (VEC == 4) load4<XT>(p.x, r * p.x_row_stride + c, x);
-            else x[0] = ld<XT>(p.x, r * p.x_row_stride + c);
+            loadv<XT, VEC>(p.x, r * p.x_row_stride + c, x);
             if (p.branch) {
                 float br[VEC], g[VEC];
-                if constexpr (VEC == 4) { load4<XT>(p.branch, r * p.branch_row_stride + c, br); load4<MT>(p.gate, b * p.mod_batch_stride + c, g); }
-                else { br[0] = ld<XT>(p.branch, r * p.branch_row_stride + c); g[0] = ld<MT>(p.gate, b * p.mod_batch_stride + c); }
+                loadv<XT, VEC>(p.branch, r * p.branch_row_stride + c, br);
+                loadv<MT, VEC>(p.gate, b * p.mod_batch_stride + c, g);
 #pragma unroll
                 for (int i = 0; i < VEC; ++i) x[i] = rnd<XT>(x[i] + g[i] * br[i]);
                 if (p.x_out) {
-                    if constexpr (VEC == 4) store4<XT>(p.x_out, r * p.x_out_row_stride + c, x);
-                    else st<XT>(p.x_out, r * p.x_out_row_stride + c, x[0]);
+                    storev<XT, VEC>(p.x_out, r * p.x_out_row_stride + c, x);
                 }
             }
             if (p.residual) {
                 float rs[VEC];
-                if constexpr (VEC == 4) load4<RT>(p.residual, r * p.res_row_stride + c, rs);
-                else rs[0] = ld<RT>(p.residual, r * p.res_row_stride + c);
+                loadv<RT, VEC>(p.residual, r * p.res_row_stride + c, rs);
 #pragma unroll
                 for (int i = 0; i < VEC; ++i) x[i] += rs[i];
             }
             if (p.residual_out) {
-                if constexpr (VEC == 4) store4<RT>(p.residual_out, r * p.res_out_row_stride + c, x);
-                else st<RT>(p.residual_out, r * p.res_out_row_stride + c, x[0]);
+                storev<RT, VEC>(p.residual_out, r * p.res_out_row_stride + c, x);
             }
 #pragma unroll
             for (int i = 0; i < VEC; ++i) { v[it][i] = x[i]; sum += x[i]; sq += x[i] * x[i]; }
@@ -114,22 +145,20 @@ __global__ __launch_bounds__(256) void add_norm_kernel(const zigma_norm_params_t
             float y[VEC], w[VEC], bs[VEC];
 #pragma unroll
             for (int i = 0; i < VEC; ++i) { w[i] = 1.f; bs[i] = 0.f; }
-            if (p.weight) { if constexpr (VEC == 4) load4<WT>(p.weight, c, w); else w[0] = ld<WT>(p.weight, c); }
-            if (p.bias) { if constexpr (VEC == 4) load4<WT>(p.bias, c, bs); else bs[0] = ld<WT>(p.bias, c); }
+            if (p.weight) loadv<WT, VEC>(p.weight, c, w);
+            if (p.bias) loadv<WT, VEC>(p.bias, c, bs);
 #pragma unroll
             for (int i = 0; i < VEC; ++i) y[i] = (v[it][i] - mean) * rstd * w[i] + bs[i];
             if (p.y_out) {
-                if constexpr (VEC == 4) store4<XT>(p.y_out, r * p.y_row_stride + c, y);
-                else st<XT>(p.y_out, r * p.y_row_stride + c, y[0]);
+                storev<XT, VEC>(p.y_out, r * p.y_row_stride + c, y);
             }
             if (p.shift) {
                 float sh[VEC], sc[VEC];
-                if constexpr (VEC == 4) { load4<MT>(p.shift, b * p.mod_batch_stride + c, sh); load4<MT>(p.scale, b * p.mod_batch_stride + c, sc); }
-                else { sh[0] = ld<MT>(p.shift, b * p.mod_batch_stride + c); sc[0] = ld<MT>(p.scale, b * p.mod_batch_stride + c); }
+                loadv<MT, VEC>(p.shift, b * p.mod_batch_stride + c, sh);
+                loadv<MT, VEC>(p.scale, b * p.mod_batch_stride + c, sc);
 #pragma unroll
                 for (int i = 0; i < VEC; ++i) y[i] = rnd<XT>(y[i]) * (1.f + sc[i]) + sh[i];
-                if constexpr (VEC == 4) store4<XT>(p.y_mod, r * p.y_mod_row_stride + c, y);
-                else st<XT>(p.y_mod, r * p.y_mod_row_stride + c, y[0]);
+                storev<XT, VEC>(p.y_mod, r * p.y_mod_row_stride + c, y);
             }
         }
     }
@@ -147,9 +176,16 @@ static int launch_norm(const zigma_norm_params_t &p, hipStream_t stream) {
                      al(p.x_out, 4 * xs) && al(p.y_out, 4 * xs) && al(p.y_mod, 4 * xs) && al(p.residual, 4 * rs) &&
                      al(p.residual_out, 4 * rs) && al(p.weight, 4 * ws) && al(p.bias, 4 * ws) && al(p.gate, 4 * ms) &&
                      al(p.shift, 4 * ms) && al(p.scale, 4 * ms);
+    const bool vec8 = vec && p.cols % 8 == 0 && p.x_row_stride % 8 == 0 && p.branch_row_stride % 8 == 0 && p.x_out_row_stride % 8 == 0 &&
+                      p.res_row_stride % 8 == 0 && p.res_out_row_stride % 8 == 0 && p.y_row_stride % 8 == 0 &&
+                      p.y_mod_row_stride % 8 == 0 && p.mod_batch_stride % 8 == 0 && al(p.x, 8 * xs) && al(p.branch, 8 * xs) &&
+                      al(p.x_out, 8 * xs) && al(p.y_out, 8 * xs) && al(p.y_mod, 8 * xs) && al(p.residual, 16) &&
+                      al(p.residual_out, 16) && al(p.weight, 8 * ws) && al(p.bias, 8 * ws) && al(p.gate, 8 * ms) &&
+                      al(p.shift, 8 * ms) && al(p.scale, 8 * ms) && xs == 2;
     dim3 grid(static_cast<unsigned>((static_cast<int64_t>(p.rows) + 3) / 4)), block(256);
 #define ZIGMA_NORM(V_, I_) hipLaunchKernelGGL((add_norm_kernel<XT, RT, WT, MT, V_, I_>), grid, block, 0, stream, p)
-    if (vec && p.cols <= 256 * 4) ZIGMA_NORM(4, 4);
+    if (vec8 && p.cols <= 512 * 2) ZIGMA_NORM(8, 2);       // 16-byte accesses for 16-bit activations
+    else if (vec && p.cols <= 256 * 4) ZIGMA_NORM(4, 4);
     else if (vec && p.cols <= 256 * 16) ZIGMA_NORM(4, 16);
     else if (p.cols <= 64 * 16) ZIGMA_NORM(1, 16);
     else if (p.cols <= 64 * 64) ZIGMA_NORM(1, 64);
