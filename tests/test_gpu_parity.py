@@ -534,3 +534,25 @@ def test_reset_period_matches_separate_sequences():
         mamba_inner_tok(xz.view(Bsz * T, K, 2 * Di).transpose(0, 1), cw, cb, xw, dw, A, D, db, perm=base + perm_t.repeat(Bsz),
                         out_rows=base + out_t.repeat(Bsz), reset_period=T, out=y.view(Bsz * T, K, Di).transpose(0, 1))
     assert rel_err(N(y), N(ref)) < 1e-6
+
+
+@pytest.mark.parametrize("Bsz,L", [(1, 1024), (2, 400), (3, 272)])
+def test_small_batch_sequence_split_matches_single_pass(Bsz, L):
+    """serving-size batches: mamba_inner_tok splits the sequence over ~768 workgroups (chunk-local states -> combine ->
+    seeded second pass); the result must equal the single-pass kernel's."""
+    import zigma_amd.selective_scan_interface as ssi
+    g = torch.Generator(device="cpu").manual_seed(L)
+    Di, R, Nst = 256, 16, 16
+    mk = lambda *s, sc=1.0: (torch.randn(*s, generator=g) * sc).to(DEV)
+    xz = mk(Bsz, L, 2 * Di)
+    cw, cb, xw, dw = mk(Di, 1, 4, sc=0.5), mk(Di, sc=0.1), mk(R + 2 * Nst, Di, sc=Di ** -0.5), mk(Di, R, sc=R ** -0.5)
+    A, D, db = -torch.exp(mk(Di, Nst, sc=0.5)), mk(Di), torch.rand(Di, generator=g).to(DEV)
+    perm = torch.randperm(L, generator=g).to(DEV, torch.int32)
+    with torch.no_grad():
+        y_split = ssi.mamba_inner_tok(xz, cw, cb, xw, dw, A, D, db, perm=perm)
+        ssi.SPLIT_SMALL_BATCH = False
+        try:
+            y_one = ssi.mamba_inner_tok(xz, cw, cb, xw, dw, A, D, db, perm=perm)
+        finally:
+            ssi.SPLIT_SMALL_BATCH = True
+    assert rel_err(N(y_split), N(y_one)) < 2e-6 and torch.isfinite(y_split).all()

@@ -23,6 +23,9 @@ from . import _lib
 from .causal_conv1d_interface import causal_conv1d_raw, conv_bwd_tok
 
 
+SPLIT_SMALL_BATCH = True     # tools/latency_probe.py flips this to measure the effect of the small-batch sequence split
+
+
 def _as_bgnl(M, name):
     """(B, N, L) -> (B, 1, N, L) like SelectiveScanFn.forward (:30-35)."""
     if M.dim() == 3:
@@ -33,7 +36,8 @@ def _as_bgnl(M, name):
 
 
 def scan_raw(u, delta, A, B, C, D=None, z=None, delta_bias=None, delta_softplus=False, *, out=None, out_z=None,
-             x=None, z_row_index=None, out_row_index=None, want_out=True, checkpoints=None, reset_period=0):
+             x=None, z_row_index=None, out_row_index=None, want_out=True, checkpoints=None, reset_period=0,
+             chunk_len=2048):
     """Launch zigma_selective_scan_fwd.  All tensors are logical (batch, dim, seqlen) VIEWS with arbitrary
     strides (token-major tensors come in as `.transpose(1, 2)`); B/C are (D, N) f32 or (B, G, N, L) views.
     Outputs that are None are allocated here with the reference's conventions (out like delta, out_z like z)."""
@@ -57,7 +61,7 @@ def scan_raw(u, delta, A, B, C, D=None, z=None, delta_bias=None, delta_softplus=
     P.batch, P.dim, P.seqlen, P.dstate = batch, dim, L, N
     P.delta_softplus = int(bool(delta_softplus))
     P.io_dtype = _lib.dtype_id(u)
-    P.chunk_len, P.flags = 2048, 0
+    P.chunk_len, P.flags = int(chunk_len), 0
     P.is_variable_B, P.is_variable_C = int(var_b), int(var_c)
     groups = 1
     bc_dt = None
@@ -117,7 +121,7 @@ def scan_raw(u, delta, A, B, C, D=None, z=None, delta_bias=None, delta_softplus=
     P.A = _lib.ptr(A)
     P.A_d_stride, P.A_dstate_stride = A.stride()
     if x is not None:
-        n_chunks = (L + 2047) // 2048
+        n_chunks = (L + int(chunk_len) - 1) // int(chunk_len)
         if x.shape != (batch, dim, n_chunks, 2 * N) or x.dtype != torch.float32 or not x.is_contiguous():
             raise RuntimeError("x must be contiguous float32 (batch, dim, n_chunks, 2*dstate)")
         P.x = _lib.ptr(x)
@@ -406,12 +410,18 @@ def mamba_inner_tok(xz, conv1d_weight, conv1d_bias, x_proj_weight, delta_proj_we
     if C_proj_bias is not None:
         Cm = Cm + C_proj_bias.to(Cm.dtype)
     y = out if out is not None else torch.empty(Bsz, L, Di, device=xz.device, dtype=xz.dtype)
-    # long sequences with few samples: hand the kernel a carry buffer so it may split the sequence over workgroups
-    xc = None
-    if L >= 4096 and Bsz * (Di // 64) < 768:
-        xc = torch.empty(Bsz, Di, (L + 2047) // 2048, 2 * N, device=xz.device, dtype=torch.float32)
+    # few workgroups (small batch, or long sequences of few samples): hand the kernel a carry buffer and a chunk length so
+    # that it splits the sequence over ~768 workgroups (3 per CU): chunk-local states -> combine -> seeded second pass
+    xc, chunk_len = None, 2048
+    wgs = Bsz * (Di // 64)
+    if not reset_period and ((SPLIT_SMALL_BATCH and wgs <= 256 and L >= 256) or (wgs < 768 and L >= 4096)):
+        if L < 4096:
+            per = -(-L // -(-768 // wgs))                         # steps per chunk that give ~768 workgroups
+            chunk_len = min(2048, max(32, (per + 15) // 16 * 16))
+        if -(-L // chunk_len) >= 2:
+            xc = torch.empty(Bsz, Di, -(-L // chunk_len), 2 * N, device=xz.device, dtype=torch.float32)
     scan_raw(u.transpose(1, 2), delta.transpose(1, 2), A, Bm.transpose(1, 2).unsqueeze(1),
              Cm.transpose(1, 2).unsqueeze(1), D, z_half.transpose(1, 2), delta_bias, delta_softplus,
              out_z=y.transpose(1, 2), z_row_index=perm, out_row_index=perm if out_rows is None else out_rows,
-             want_out=False, x=xc, reset_period=reset_period)
+             want_out=False, x=xc, reset_period=reset_period, chunk_len=chunk_len)
     return y
