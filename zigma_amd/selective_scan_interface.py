@@ -24,6 +24,7 @@ from .causal_conv1d_interface import causal_conv1d_raw, conv_bwd_tok
 
 
 SPLIT_SMALL_BATCH = True     # tools/latency_probe.py flips this to measure the effect of the small-batch sequence split
+SPLIT_MAX_WGS = 200          # ... and sweeps this: split when batch * d_inner / 64 is at most this many workgroups (tools/split_threshold_probe.py)
 
 
 def _as_bgnl(M, name):
@@ -414,7 +415,7 @@ def mamba_inner_tok(xz, conv1d_weight, conv1d_bias, x_proj_weight, delta_proj_we
     # that it splits the sequence over ~768 workgroups (3 per CU): chunk-local states -> combine -> seeded second pass
     xc, chunk_len = None, 2048
     wgs = Bsz * (Di // 64)
-    if not reset_period and ((SPLIT_SMALL_BATCH and wgs <= 256 and L >= 256) or (wgs < 768 and L >= 4096)):
+    if not reset_period and ((SPLIT_SMALL_BATCH and wgs <= SPLIT_MAX_WGS and L >= 256) or (wgs < 768 and L >= 4096)):
         if L < 4096:
             per = -(-L // -(-768 // wgs))                         # steps per chunk that give ~768 workgroups
             chunk_len = min(2048, max(32, (per + 15) // 16 * 16))
