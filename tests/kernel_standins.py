@@ -25,7 +25,8 @@ def conv_raw(x, weight, bias, silu, *, out=None, x_row_index=None, reset_period=
 
 
 def scan_raw(u, delta, A, B, C, D=None, z=None, delta_bias=None, delta_softplus=False, *, out=None, out_z=None,
-             x=None, z_row_index=None, out_row_index=None, want_out=True, checkpoints=None, reset_period=0):
+             x=None, z_row_index=None, out_row_index=None, want_out=True, checkpoints=None, reset_period=0,
+             chunk_len=2048):
     assert not reset_period and checkpoints is None, "stand-in: GPU-only features"
     zs = _np(z)
     if zs is not None and z_row_index is not None:
