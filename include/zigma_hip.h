@@ -184,7 +184,7 @@ int zigma_add_norm_fwd(const zigma_norm_params_t *p, void *stream);
  *
  * x: (m, >=k) rows of pitch x_row_stride (the first k columns of x_dbl);  w: (n, k) = dt_proj.weight;
  * bias: float32 (n) or NULL;  out: (m, n).  The selective scan is then called with delta_softplus = 0 and
- * delta_bias = NULL.  Limits: dtype bf16, k <= 48, n % 64 == 0, x/w rows 16-byte aligned.
+ * delta_bias = NULL.  Limits: dtype bf16, k <= 48 and a multiple of 8, n % 64 == 0, x/w rows 16-byte aligned.
  * ------------------------------------------------------------------------------------------ */
 typedef struct zigma_dtproj_params {
     int64_t m;              /* tokens (batch * seqlen) */

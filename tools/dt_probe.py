@@ -13,14 +13,4 @@ def timeit(fn, iters=30):
     e1.record(); torch.cuda.synchronize(); return e0.elapsed_time(e1) / iters * 1e3
 print("softplus on ", round(timeit(lambda: dt_proj_softplus(xdbl, R, w, db, True)), 1), "us")
 print("softplus off", round(timeit(lambda: dt_proj_softplus(xdbl, R, w, db, False)), 1), "us")
-import zigma_amd._lib as _lib
-orig = _lib.call
-mode = [1]
-def call(name, P, d):
-    if name == "zigma_dt_proj_softplus_fwd": P.softplus = mode[0]
-    return orig(name, P, d)
-_lib.call = call
-for m, nm in ((0, "plain"), (2, "no stores"), (3, "no mfma (stores only)")):
-    mode[0] = m
-    print(nm, round(timeit(lambda: dt_proj_softplus(xdbl, R, w, db, True)), 1), "us")
 print("empty alloc ", round(timeit(lambda: torch.empty(B * L, Di, device=dev, dtype=dt)), 1), "us")

@@ -32,17 +32,12 @@ __global__ __launch_bounds__(64 * kDtWaves) void dt_proj_softplus_kernel(const z
     uint16_t *ow = reinterpret_cast<uint16_t *>(p.out);
     const float *bias = reinterpret_cast<const float *>(p.bias);
 
-    auto frag = [&](const uint16_t *row, int k0) -> bf16x8 {  // 8 consecutive k of one row, zero beyond K
-        uint4 v = make_uint4(0, 0, 0, 0);
-        if (k0 + 8 <= p.k) {
-            v = *reinterpret_cast<const uint4 *>(row + k0);
-        } else if (k0 < p.k) {
-            uint16_t t[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-            for (int i = 0; i < 8; ++i)
-                if (k0 + i < p.k) t[i] = row[k0 + i];
-            __builtin_memcpy(&v, t, 16);
-        }
-        return __builtin_bit_cast(bf16x8, v);
+    // 8 consecutive k of one row; k % 8 == 0 (dispatcher), so a fragment is either whole or beyond K (= zero): the
+    // address is clamped and the value selected — no divergent branches around the loads
+    auto frag = [&](const uint16_t *row, int k0) -> bf16x8 {
+        const bool live = k0 < p.k;
+        const uint4 v = *reinterpret_cast<const uint4 *>(row + (live ? k0 : 0));
+        return __builtin_bit_cast(bf16x8, live ? v : make_uint4(0, 0, 0, 0));
     };
     // B fragments (weights) of this block's channels: even / odd channel per lane, 3 k-steps, loaded once
     bf16x8 be[3], bo[3];
@@ -71,15 +66,15 @@ __global__ __launch_bounds__(64 * kDtWaves) void dt_proj_softplus_kernel(const z
             co = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bo[s], co, 0, 0, 0);
         }
         // C/D layout: column = lane & 31 (channel pair j), row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5) (token)
+        const bool full = m0 + kDtTokPerWave <= p.m;            // wave-uniform: whole tile inside -> no per-store predicate
+        uint16_t *orow = ow + (m0 + 4 * kh) * p.out_row_stride + d0 + 2 * j;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const int64_t m = m0 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+            const int dm = (r & 3) + 8 * (r >> 2);
             float ve = ce[r] + b_e, vo = co[r] + b_o;
             if (p.softplus) { ve = softplus20(ve); vo = softplus20(vo); }
-            if (m < p.m) {
-                const uint32_t pk = static_cast<uint32_t>(from_float<BF16>(ve)) | (static_cast<uint32_t>(from_float<BF16>(vo)) << 16);
-                *reinterpret_cast<uint32_t *>(ow + m * p.out_row_stride + d0 + 2 * j) = pk;
-            }
+            const uint32_t pk = static_cast<uint32_t>(from_float<BF16>(ve)) | (static_cast<uint32_t>(from_float<BF16>(vo)) << 16);
+            if (full || m0 + 4 * kh + dm < p.m) *reinterpret_cast<uint32_t *>(orow + dm * p.out_row_stride) = pk;
         }
     }
 }
@@ -97,7 +92,7 @@ extern "C" int zigma_dt_proj_softplus_fwd(const zigma_dtproj_params_t *pp, void 
     if (p.m == 0 || p.n == 0) return ZIGMA_OK;
     if (!p.x || !p.w || !p.out) return ZIGMA_ERR_NULL;
     if (p.dtype != ZIGMA_BF16) return ZIGMA_ERR_DTYPE;
-    if (p.k > 48 || p.n % kDtChPerBlock != 0) return ZIGMA_ERR_SHAPE;
+    if (p.k > 48 || p.k % 8 != 0 || p.n % kDtChPerBlock != 0) return ZIGMA_ERR_SHAPE;
     // 16-byte fragment loads, 4-byte packed stores
     if (p.x_row_stride % 8 != 0 || p.w_row_stride % 8 != 0 || p.out_row_stride % 2 != 0 ||
         reinterpret_cast<uintptr_t>(p.x) % 16 != 0 || reinterpret_cast<uintptr_t>(p.w) % 16 != 0 ||

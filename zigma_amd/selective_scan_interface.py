@@ -141,8 +141,9 @@ def scan_raw(u, delta, A, B, C, D=None, z=None, delta_bias=None, delta_softplus=
 
 
 def dt_proj_eligible(x_dbl, dt_rank, weight):
-    """bf16 token-major x_dbl rows / weight rows on 16-byte boundaries, d_inner a multiple of 64, dt_rank <= 48."""
+    """bf16 token-major x_dbl rows / weight rows on 16-byte boundaries, d_inner a multiple of 64, dt_rank <= 48, % 8 == 0."""
     return (x_dbl.is_cuda and x_dbl.dtype == torch.bfloat16 and weight.dtype == torch.bfloat16 and dt_rank <= 48
+            and dt_rank % 8 == 0
             and weight.shape[0] % 64 == 0 and x_dbl.stride(-1) == 1 and weight.stride(1) == 1
             and x_dbl.stride(-2) % 8 == 0 and weight.stride(0) % 8 == 0
             and x_dbl.data_ptr() % 16 == 0 and weight.data_ptr() % 16 == 0)
