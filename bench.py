@@ -180,7 +180,6 @@ def main():
     timer.enabled = False
 
     if rank == 0:
-        from zigma_amd import _lib
         Di, N = 2 * wl["model"]["embed_dim"], 16
         algo_bytes = batch * L * (4 * 2 * Di + 2 * 2 * N) + 4 * Di * (N + 2)
         roof = None

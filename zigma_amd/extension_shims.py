@@ -18,7 +18,6 @@ does not.  `causal_conv1d_update` (recurrent decoding) is out of scope and raise
 import sys
 import types
 
-import torch
 import torch.nn.functional as F
 
 from .causal_conv1d_interface import causal_conv1d_fwd, conv_bwd_tok
