@@ -347,6 +347,24 @@ typedef struct zigma_xattn_params {
 
 int zigma_cross_attn_fwd(const zigma_xattn_params_t *p, void *stream);
 
+/* ------------------------------------------------------------------------------------------
+ * x_proj: out[m, n] = sum_k x[m, k] * w[n, k]  for the skinny projection of the Mamba block (n = dt_rank + 2 d_state).
+ * Replaces F.linear(conv1d_out, x_proj_weight) (reference dis_mamba/mamba_ssm/ops/selective_scan_interface.py:318-322).
+ * x: (m, k) rows (the conv output u, token-major); w: (n, k) = x_proj.weight; out: (m, n).  bf16 in, fp32 accumulate,
+ * bf16 out.  Limits: n <= 96, k % 256 == 0, x / w rows 16-byte aligned.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct zigma_xproj_params {
+    int64_t m;
+    int32_t n, k;
+    int32_t dtype;
+    int32_t flags;           /* reserved, must be 0 */
+    int64_t x_row_stride, w_row_stride, out_row_stride;
+    const void *x, *w;
+    void *out;
+} zigma_xproj_params_t;
+
+int zigma_x_proj_fwd(const zigma_xproj_params_t *p, void *stream);
+
 /* ------------------------------------------------------------------------------------------ */
 const char *zigma_strerror(int status);
 int zigma_abi_version(void);

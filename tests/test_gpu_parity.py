@@ -445,6 +445,22 @@ def test_graphed_forward_matches_eager_and_sampler_runs_on_it():
         gf(x[:1], t[:1], y[:1])
 
 
+@pytest.mark.parametrize("M,K,Nn", [(1, 256, 72), (300, 1280, 72), (4096, 1536, 80), (257, 512, 96), (64, 256, 40)])
+def test_x_proj_kernel_vs_oracle(M, K, Nn):
+    """x_dbl = u @ W_x^T with the read-bound MFMA kernel vs float64 numpy on the same bf16 operands (output rounded to bf16)."""
+    from zigma_amd import _lib
+    from zigma_amd.selective_scan_interface import x_proj, x_proj_eligible
+    rng = np.random.default_rng(M + K)
+    u = zo.bf16_round(rng.standard_normal((M, K)).astype(np.float32))
+    w = zo.bf16_round((rng.standard_normal((Nn, K)) * K ** -0.5).astype(np.float32))
+    ut, wt = T(u, torch.bfloat16), T(w, torch.bfloat16)
+    assert x_proj_eligible(ut, wt)
+    out = x_proj(ut, wt)
+    assert _lib.last_kernel() == "x_proj_mfma" and out.shape == (M, Nn)
+    ref = zo.bf16_round((u.astype(np.float64) @ w.astype(np.float64).T).astype(np.float32))
+    assert rel_err(N(out), ref) < 3e-3 and np.allclose(N(out), ref, rtol=2e-2, atol=2e-2)
+
+
 @pytest.mark.parametrize("Bsz,L,H,NC", [(2, 100, 8, 77), (1, 64, 3, 128), (3, 17, 8, 5), (2, 256, 8, 81)])
 def test_cross_attn_kernel_vs_oracle(Bsz, L, H, NC):
     """softmax(scale Q K^T) V per head on the matrix cores vs a float64 numpy evaluation on the same bf16 operands; K / V

@@ -24,6 +24,7 @@ from .causal_conv1d_interface import causal_conv1d_raw, conv_bwd_tok
 
 
 SPLIT_SMALL_BATCH = True     # tools/latency_probe.py flips this to measure the effect of the small-batch sequence split
+USE_X_PROJ_KERNEL = True      # own MFMA kernel for the skinny x_proj instead of the library GEMM (same speed stand-alone)
 SPLIT_MAX_WGS = 200          # ... and sweeps this: split when batch * d_inner / 64 is at most this many workgroups (tools/split_threshold_probe.py)
 
 
@@ -138,6 +139,28 @@ def scan_raw(u, delta, A, B, C, D=None, z=None, delta_bias=None, delta_softplus=
     P.reset_period = int(reset_period)       # > 0: independent sequences of that many steps along seqlen
     _lib.call("zigma_selective_scan_fwd", P, dev)
     return out, out_z
+
+
+def x_proj_eligible(u, weight):
+    """limits of zigma_x_proj_fwd: bf16, n <= 96, k % 256 == 0, 16-byte aligned contiguous rows"""
+    return (u.is_cuda and u.dtype == torch.bfloat16 and weight.dtype == torch.bfloat16 and u.is_contiguous()
+            and weight.shape[0] <= 96 and weight.shape[1] % 256 == 0 and weight.stride(1) == 1 and weight.stride(0) % 8 == 0
+            and u.data_ptr() % 16 == 0 and weight.data_ptr() % 16 == 0)
+
+
+def x_proj(u, weight):
+    """x_dbl = u @ weight.T on the matrix cores with a kernel shaped for the skinny output (zigma_x_proj_fwd)."""
+    dev = _lib.require_device(u, weight)
+    lead, K = u.shape[:-1], u.shape[-1]
+    u2 = u.reshape(-1, K)
+    n = weight.shape[0]
+    out = torch.empty(u2.shape[0], n, device=u.device, dtype=u.dtype)
+    P = _lib.XProjParams()
+    P.m, P.n, P.k, P.dtype, P.flags = u2.shape[0], n, K, _lib.dtype_id(u), 0
+    P.x_row_stride, P.w_row_stride, P.out_row_stride = u2.stride(0), weight.stride(0), out.stride(0)
+    P.x, P.w, P.out = _lib.ptr(u2), _lib.ptr(weight), _lib.ptr(out)
+    _lib.call("zigma_x_proj_fwd", P, dev)
+    return out.reshape(*lead, n)
 
 
 def dt_proj_eligible(x_dbl, dt_rank, weight):
@@ -399,7 +422,10 @@ def mamba_inner_tok(xz, conv1d_weight, conv1d_bias, x_proj_weight, delta_proj_we
     u = torch.empty(Bsz, L, Di, device=xz.device, dtype=xz.dtype)
     causal_conv1d_raw(x_half.transpose(1, 2), w, conv1d_bias, True, out=u.transpose(1, 2), x_row_index=perm,
                       reset_period=reset_period)
-    x_dbl = F.linear(u, x_proj_weight)                               # (B, L, R + 2N)   GEMM
+    if USE_X_PROJ_KERNEL and x_proj_eligible(u, x_proj_weight):
+        x_dbl = x_proj(u, x_proj_weight)                                 # (B, L, R + 2N)   read-bound MFMA kernel
+    else:
+        x_dbl = F.linear(u, x_proj_weight)                               # (B, L, R + 2N)   GEMM
     fused_dt = delta_softplus and dt_proj_eligible(x_dbl, R, delta_proj_weight)
     if fused_dt:   # K = dt_rank GEMM + bias + softplus in one write-bound MFMA kernel; scan skips its softplus
         delta = dt_proj_softplus(x_dbl, R, delta_proj_weight, delta_bias, True)
