@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define ZIGMA_ABI_VERSION 1
+#define ZIGMA_ABI_VERSION 2   /* 2: parameter blocks grew (row tables in the backward, checkpoints, reset_period) */
 
 typedef enum zigma_status {
     ZIGMA_OK = 0,

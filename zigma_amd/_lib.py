@@ -145,7 +145,7 @@ def lib():
         L.zigma_strerror.restype = C.c_char_p
         L.zigma_abi_version.restype = C.c_int
         L.zigma_last_kernel.restype = C.c_char_p
-        if L.zigma_abi_version() != 1:
+        if L.zigma_abi_version() != 2:
             raise RuntimeError("zigma_amd: libzigma_hip.so ABI version mismatch")
         _lib = L
     return _lib
