@@ -26,7 +26,8 @@ def main():
     names = {0: "exp2 x8", 1: "pk_fma x8", 2: "fma x8", 3: "mix 8 exp + 16 pk_fma (one wave)",
              4: "split waves: even exp x8 / odd pk_fma x16", 5: "soft exp2 (pk) x16 values", 6: "log2 x8", 7: "rcp x8",
              8: "mix 8 exp + 16 scalar fma", 9: "mul_dpp row_newbcast x8", 10: "fmac_dpp row_newbcast x8",
-             11: "scan core replica: 2 steps x 4 states (40 VALU incl 8 exp)"}
+             11: "scan core replica: 2 steps x 4 states (40 VALU incl 8 exp)", 12: "exp_f16 x8", 13: "rcp_f16 x8",
+             14: "pk_mul_f16 x8"}
     clk = 2.4e9
     res = {}
     iters = 4000

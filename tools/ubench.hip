@@ -124,6 +124,39 @@ __global__ __launch_bounds__(256) void k_rate(float *out, int iters, float seed)
         ITER_BODY_END
         x[0] = hh[0] + y; x[1] = hh[1]; x[2] = hh[2]; x[3] = hh[3];
     }
+    else if (MODE == 12) {  // v_exp_f16, 8 independent (is the 16-bit transcendental any faster?)
+        _Float16 hx[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) hx[i] = static_cast<_Float16>(x[i]);
+        ITER_BODY_BEGIN
+#pragma unroll
+        for (int i = 0; i < 8; ++i) asm volatile("v_exp_f16 %0, %0" : "+v"(hx[i]));
+        ITER_BODY_END
+#pragma unroll
+        for (int i = 0; i < 8; ++i) x[i] = static_cast<float>(hx[i]);
+    } else if (MODE == 13) {  // v_rcp_f16
+        _Float16 hx[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) hx[i] = static_cast<_Float16>(x[i]);
+        ITER_BODY_BEGIN
+#pragma unroll
+        for (int i = 0; i < 8; ++i) asm volatile("v_rcp_f16 %0, %0" : "+v"(hx[i]));
+        ITER_BODY_END
+#pragma unroll
+        for (int i = 0; i < 8; ++i) x[i] = static_cast<float>(hx[i]);
+    } else if (MODE == 14) {  // v_pk_mul_f16 (packed 16-bit pipe)
+        typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+        h2 hp[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) hp[i] = h2{static_cast<_Float16>(x[i]), static_cast<_Float16>(x[i] + 0.5f)};
+        const h2 hc = {static_cast<_Float16>(0.999f), static_cast<_Float16>(0.998f)};
+        ITER_BODY_BEGIN
+#pragma unroll
+        for (int i = 0; i < 8; ++i) asm volatile("v_pk_mul_f16 %0, %0, %1" : "+v"(hp[i]) : "v"(hc));
+        ITER_BODY_END
+#pragma unroll
+        for (int i = 0; i < 8; ++i) x[i] = static_cast<float>(hp[i].x) + static_cast<float>(hp[i].y);
+    }
     float s = 0.f;
 #pragma unroll
     for (int i = 0; i < 8; ++i) s += x[i] + p[i].x + p[i].y;
@@ -146,6 +179,9 @@ extern "C" int ubench_launch(int mode, int blocks, int iters, float *out, void *
         case 9: hipLaunchKernelGGL(k_rate<9>, g, b, 0, st, out, iters, 0.5f); break;
         case 10: hipLaunchKernelGGL(k_rate<10>, g, b, 0, st, out, iters, 0.5f); break;
         case 11: hipLaunchKernelGGL(k_rate<11>, g, b, 0, st, out, iters, 0.5f); break;
+        case 12: hipLaunchKernelGGL(k_rate<12>, g, b, 0, st, out, iters, 0.5f); break;
+        case 13: hipLaunchKernelGGL(k_rate<13>, g, b, 0, st, out, iters, 0.5f); break;
+        case 14: hipLaunchKernelGGL(k_rate<14>, g, b, 0, st, out, iters, 0.5f); break;
         default: return -1;
     }
     return hipGetLastError() == hipSuccess ? 0 : -5;
