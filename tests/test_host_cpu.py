@@ -279,3 +279,16 @@ def test_extension_shims_under_the_reference_python(monkeypatch):
                                  T("out_proj_b"), T("A"), None, None, T("D"), delta_bias=T("delta_bias"),
                                  delta_softplus=True)
     assert rel_err(out.numpy(), g["out"]) < 5e-6
+
+
+def test_sequence_split_policy():
+    """host-side choice of the scan's sequence split (no GPU): only when the plain grid cannot fill the chip."""
+    from zigma_amd.selective_scan_interface import split_chunk_len
+    assert split_chunk_len(64, 1280, 1024) == 0                      # headline batch: 1280 workgroups, single pass
+    assert split_chunk_len(1, 1280, 1024) == 32                      # one sample: 20 workgroups -> 32 chunks of 32 steps
+    assert split_chunk_len(4, 1280, 1024) == 112 and split_chunk_len(16, 1280, 1024) == 0
+    assert split_chunk_len(4, 1280, 16384) == 2048 and split_chunk_len(64, 1280, 16384) == 0
+    assert split_chunk_len(1, 1280, 128) == 0 and split_chunk_len(2, 1536, 4096, reset_period=16) == 0
+    for b in range(1, 11):
+        c = split_chunk_len(b, 1280, 1024)
+        assert c % 16 == 0 and c >= 32 and -(-1024 // c) >= 2

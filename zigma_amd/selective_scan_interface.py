@@ -28,6 +28,23 @@ USE_X_PROJ_KERNEL = True      # own MFMA kernel for the skinny x_proj instead of
 SPLIT_MAX_WGS = 200          # ... and sweeps this: split when batch * d_inner / 64 is at most this many workgroups (tools/split_threshold_probe.py)
 
 
+def split_chunk_len(batch, d_inner, seqlen, reset_period=0):
+    """Chunk length (a multiple of 16) for the sequence-split mode of the token-major scan, or 0 for a single pass.
+    The plain grid is batch * d_inner / 64 workgroups; the split pays (it runs the recurrence twice) only when that
+    leaves most of the 256 CUs idle: small batches at L >= 256 (threshold from tools/split_threshold_probe.py), or
+    long sequences (L >= 4096, the reference's own 2048-step chunks)."""
+    wgs = batch * (d_inner // 64)
+    if reset_period or wgs < 1:
+        return 0
+    if seqlen >= 4096:
+        return 2048 if wgs < 768 else 0
+    if not (SPLIT_SMALL_BATCH and wgs <= SPLIT_MAX_WGS and seqlen >= 256):
+        return 0
+    per = -(-seqlen // -(-768 // wgs))                            # steps per chunk that give ~768 workgroups
+    chunk = min(2048, max(32, (per + 15) // 16 * 16))
+    return chunk if -(-seqlen // chunk) >= 2 else 0
+
+
 def _as_bgnl(M, name):
     """(B, N, L) -> (B, 1, N, L) like SelectiveScanFn.forward (:30-35)."""
     if M.dim() == 3:
@@ -440,14 +457,11 @@ def mamba_inner_tok(xz, conv1d_weight, conv1d_bias, x_proj_weight, delta_proj_we
     y = out if out is not None else torch.empty(Bsz, L, Di, device=xz.device, dtype=xz.dtype)
     # few workgroups (small batch, or long sequences of few samples): hand the kernel a carry buffer and a chunk length so
     # that it splits the sequence over ~768 workgroups (3 per CU): chunk-local states -> combine -> seeded second pass
-    xc, chunk_len = None, 2048
-    wgs = Bsz * (Di // 64)
-    if not reset_period and ((SPLIT_SMALL_BATCH and wgs <= SPLIT_MAX_WGS and L >= 256) or (wgs < 768 and L >= 4096)):
-        if L < 4096:
-            per = -(-L // -(-768 // wgs))                         # steps per chunk that give ~768 workgroups
-            chunk_len = min(2048, max(32, (per + 15) // 16 * 16))
-        if -(-L // chunk_len) >= 2:
-            xc = torch.empty(Bsz, Di, -(-L // chunk_len), 2 * N, device=xz.device, dtype=torch.float32)
+    xc, chunk_len = None, split_chunk_len(Bsz, Di, L, reset_period)
+    if chunk_len:
+        xc = torch.empty(Bsz, Di, -(-L // chunk_len), 2 * N, device=xz.device, dtype=torch.float32)
+    else:
+        chunk_len = 2048
     scan_raw(u.transpose(1, 2), delta.transpose(1, 2), A, Bm.transpose(1, 2).unsqueeze(1),
              Cm.transpose(1, 2).unsqueeze(1), D, z_half.transpose(1, 2), delta_bias, delta_softplus,
              out_z=y.transpose(1, 2), z_row_index=perm, out_row_index=perm if out_rows is None else out_rows,
