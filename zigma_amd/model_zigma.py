@@ -37,6 +37,36 @@ def modulate(x, shift, scale):
     return x * (1 + scale.unsqueeze(1)) + shift.unsqueeze(1)
 
 
+class _ModulateFn(torch.autograd.Function):
+    """modulate() for the differentiable path with a hand-written backward: 1 + 3 launches instead of the ~8 of the
+    autograd graph of `x * (1 + scale) + shift`."""
+
+    @staticmethod
+    def forward(ctx, x, shift, scale):
+        ctx.save_for_backward(x, scale)
+        return torch.addcmul(shift.unsqueeze(1), x, (1 + scale).unsqueeze(1))
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, scale = ctx.saved_tensors
+        dx = dy * (1 + scale).unsqueeze(1)
+        return dx, dy.sum(1), (dy * x).sum(1)
+
+
+class _GatedAddFn(torch.autograd.Function):
+    """base + gate[:, None, :] * branch with a hand-written backward."""
+
+    @staticmethod
+    def forward(ctx, base, gate, branch):
+        ctx.save_for_backward(gate, branch)
+        return torch.addcmul(base, gate.unsqueeze(1), branch)
+
+    @staticmethod
+    def backward(ctx, dy):
+        gate, branch = ctx.saved_tensors
+        return dy, (dy * branch).sum(1), dy * gate.unsqueeze(1)
+
+
 class PatchEmbed(nn.Module):
     """2D image -> patch tokens (timm's PatchEmbed surface: .proj conv weights, .num_patches, .patch_size).
     The strided conv is evaluated as unfold + GEMM (kernel == stride, so the two are the same map)."""
@@ -263,10 +293,10 @@ class Block(nn.Module):
         x, residual = fn(x if residual is None else self.drop_path(x), self.norm.weight, self.norm.bias, residual=residual,
                          prenorm=True, residual_in_fp32=self.residual_in_fp32, eps=self.norm.eps)
         mod = self.adaLN_modulation(c).chunk(6 if self.has_text else 3, dim=1)
-        x = x + mod[2].unsqueeze(1) * self.mixer(modulate(x, mod[0], mod[1]))
+        x = _GatedAddFn.apply(x, mod[2], self.mixer(_ModulateFn.apply(x, mod[0], mod[1])))
         if self.has_text:
-            xa = modulate(layer_norm_fn(x, None, None, eps=self.norm_msa.eps), mod[3], mod[4])
-            x = x + mod[5].unsqueeze(1) * self.msa(xa, text=text, mask=None)
+            xa = _ModulateFn.apply(layer_norm_fn(x, None, None, eps=self.norm_msa.eps), mod[3], mod[4])
+            x = _GatedAddFn.apply(x, mod[5], self.msa(xa, text=text, mask=None))
         return x, residual
 
 
