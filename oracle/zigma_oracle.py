@@ -13,8 +13,8 @@ the seed-0 known answers of the reference's own `test_selective_scan.py` fixture
 and against the integer digests of the scan-order tables.
 Parity status: op level + model level PINNED (golden vectors from the reference run here);
 `torchdiffeq.odeint` (third party, unpinned version, absent from /root/reference) is
-restated from its published algorithm — fixed-grid Euler / midpoint / Heun / RK4 — and
-that sampler-trajectory parity is UNPINNED (no reference test or vendored source exists).
+restated from its published algorithm — fixed-grid Euler / midpoint / Heun / RK4 and the adaptive
+dopri5 controller — and that sampler-trajectory parity is UNPINNED (no reference test or vendored source exists).
 
 All math is done in `dt` (float32 by default, float64 on request).
 """
@@ -492,6 +492,71 @@ def sample_ode_fixed(model_fn, x0, num_steps=50, method="euler", t0=0.0, t1=1.0,
             raise ValueError(method)
         traj.append(x)
     return np.stack(traj)
+
+
+def sample_ode_dopri5(model_fn, x0, num_steps=50, rtol=1e-3, atol=1e-6, t0=0.0, t1=1.0, dt=np.float64):
+    """Adaptive Dormand-Prince 5(4) as torchdiffeq runs it for the reference's default `sampling_method="dopri5"`
+    (config/ode/ode.yaml:2-5, transport/integrators.py:122) — restated from the published algorithm, UNPINNED (the
+    package is absent).  Plain Python control flow, every quantity a host number: the independent check for the
+    product's on-device controller.  Returns (trajectory at linspace(t0, t1, num_steps), nfe, accepted, rejected).
+
+    Controller: h0 by Hairer's rule with exponent 1/5; error ratio = RMS(err / (atol + rtol max(|y0|, |y1|)));
+    accept iff ratio <= 1; h *= min(10, max(0.9 ratio^-1/5, 0.2 — or 1 when accepted with ratio < 1)); steps never
+    clamp to output times; outputs by the quartic dense output through (y0, y(t+h/2), y1, f0, f1)."""
+    A_ = [[], [1 / 5], [3 / 40, 9 / 40], [44 / 45, -56 / 15, 32 / 9],
+          [19372 / 6561, -25360 / 2187, 64448 / 6561, -212 / 729],
+          [9017 / 3168, -355 / 33, 46732 / 5247, 49 / 176, -5103 / 18656],
+          [35 / 384, 0.0, 500 / 1113, 125 / 192, -2187 / 6784, 11 / 84]]
+    C_ = [0.0, 1 / 5, 3 / 10, 4 / 5, 8 / 9, 1.0, 1.0]
+    B5 = [35 / 384, 0.0, 500 / 1113, 125 / 192, -2187 / 6784, 11 / 84, 0.0]
+    B4 = [1951 / 21600, 0.0, 22642 / 50085, 451 / 720, -12231 / 42400, 649 / 6300, 1 / 60]
+    MID = [6025192743 / 30085553152 / 2, 0.0, 51252292925 / 65400821598 / 2, -2691868925 / 45128329728 / 2,
+           187940372067 / 1594534317056 / 2, -1776094331 / 19743644256 / 2, 11237099 / 235043384 / 2]
+    ts = np.linspace(t0, t1, num_steps).astype(np.float32).astype(np.float64)     # th.linspace is float32
+    y = np.asarray(x0, dtype=dt)
+    ones = np.ones(y.shape[0], dtype=np.float32)
+    f = lambda tt, yy: np.asarray(model_fn(yy, ones * np.float32(tt)), dtype=dt)
+    rms = lambda v: float(np.sqrt(np.mean(np.square(v.astype(np.float64)))))
+    t = float(ts[0])
+    f0 = f(t, y)
+    scale = atol + np.abs(y) * rtol
+    d0, d1 = rms(y / scale), rms(f0 / scale)
+    h0 = 1e-6 if (d0 < 1e-5 or d1 < 1e-5) else 0.01 * d0 / d1
+    f1 = f(t + h0, y + h0 * f0)
+    d2 = rms((f1 - f0) / scale) / h0
+    h1 = max(1e-6, h0 * 1e-3) if (d1 <= 1e-15 and d2 <= 1e-15) else (0.01 / max(d1, d2)) ** (1.0 / 5)
+    h = min(100 * h0, h1)
+    nfe, acc, rej = 2, 0, 0
+    traj, nxt = [y], 1
+    while nxt < len(ts):
+        ks = [f0]
+        for i in range(1, 7):
+            yi = y + h * sum(a * k for a, k in zip(A_[i], ks) if a != 0.0)
+            ks.append(f(t + C_[i] * h, yi))
+        nfe += 6
+        y1 = y + h * sum(b * k for b, k in zip(B5, ks) if b != 0.0)
+        err = h * sum((b5 - b4) * k for b5, b4, k in zip(B5, B4, ks) if b5 != b4)
+        ratio = rms(err / (atol + rtol * np.maximum(np.abs(y), np.abs(y1))))
+        if ratio <= 1:
+            acc += 1
+            ymid = y + h * sum(m * k for m, k in zip(MID, ks) if m != 0.0)
+            fn = ks[-1]
+            ca = 2 * h * (fn - f0) - 8 * (y1 + y) + 16 * ymid
+            cb = h * (5 * f0 - 3 * fn) + 18 * y + 14 * y1 - 32 * ymid
+            cc = h * (fn - 4 * f0) - 11 * y - 5 * y1 + 16 * ymid
+            while nxt < len(ts) and ts[nxt] <= t + h:
+                s = (ts[nxt] - t) / h
+                traj.append(y + s * (h * f0) + s ** 2 * cc + s ** 3 * cb + s ** 4 * ca)
+                nxt += 1
+            t, y, f0 = t + h, y1, fn
+        else:
+            rej += 1
+        if ratio == 0:
+            fac = 10.0
+        else:
+            fac = min(10.0, max(0.9 / ratio ** 0.2, 1.0 if ratio < 1 else 0.2))
+        h *= fac
+    return np.stack(traj), nfe, acc, rej
 
 
 # ---------------------------------------------------------------------------------------------------

@@ -152,6 +152,16 @@ def test_transport_rules_and_fixed_grid_solvers():
     for method, tol in (("dopri5", 1e-4), ("bosh3", 2e-3), ("adaptive_heun", 2e-2)):
         got = Sampler(tr).sample_ode(sampling_method=method, num_steps=4, rtol=1e-5, atol=1e-8)(x0, model)
         assert got.shape == (4, 2, 2) and rel_err(got[-1].numpy(), exact.numpy()) < tol, method
+    # the adaptive controller (torchdiffeq's rules, restated) against the independent float64 host restatement in the
+    # oracle: same accepted / rejected sequence, same NFE, same trajectory; one host read per step, none elsewhere
+    from zigma_amd.transport import integrators as integ
+    stiff = lambda x, t: -x * (1 + t.view(-1, 1)) + torch.sin(3 * x)
+    got = Sampler(tr).sample_ode(sampling_method="dopri5", num_steps=7, rtol=1e-3, atol=1e-6)(x0, stiff)
+    st = integ.AdaptiveStats
+    ref, nfe, acc, rej = zo.sample_ode_dopri5(lambda x, t: -x * (1 + t[:, None]) + np.sin(3 * x), x0.numpy(), num_steps=7)
+    assert (st.nfe, st.accepted, st.steps - st.accepted) == (nfe, acc, rej) and rej > 0
+    assert st.host_reads == st.steps
+    assert got.shape == (7, 2, 2) and np.abs(got.numpy() - ref).max() < 1e-6
     rev = Sampler(tr).sample_ode(sampling_method="euler", num_steps=3, reverse=True)(x0, lambda x, t: torch.ones_like(x))
     assert torch.allclose(rev[-1], x0 - 1)                    # reverse integrates from t=1 down to 0
     # likelihood ODE on a field with a known divergence: v(x, t) = a x  ->  div = a * dim exactly (Rademacher probes give
@@ -245,6 +255,35 @@ def test_module_plumbing_with_oracle_standins(name, monkeypatch):
     with torch.no_grad():
         out = m(torch.from_numpy(g["x"]), torch.from_numpy(g["t"]), y)
     assert rel_err(out.numpy(), g["out"]) < 2e-5, rel_err(out.numpy(), g["out"])
+
+
+def test_drop_path_is_applied_once_per_block_in_train_mode(monkeypatch):
+    """Stochastic depth (reference model_zigma.py:406-437,963-975): once per block on the incoming branch when a residual
+    stream exists, once before the final norm.  DropPath is mocked to the deterministic x -> 2x so a double application
+    shows up as a factor; the fused_add_norm=True path must equal the literal non-fused composition."""
+    import kernel_standins
+    from zigma_amd import model_zigma as mz
+    kernel_standins.install(monkeypatch)
+    calls = []
+    monkeypatch.setattr(mz.DropPath, "forward", lambda self, x: (calls.append(1), x * 2.0)[1])
+    g = load_golden("zigma_uncond_zigzag8.npz")
+    cfg = dict(ast.literal_eval(str(g["cfg"])), drop_path_rate=0.5)
+    sd = {k[3:]: torch.from_numpy(v) for k, v in g.items() if k.startswith("sd.")}
+    outs = []
+    for fused in (True, False):
+        m = mz.ZigMa(device="cpu", **dict(cfg, fused_add_norm=fused)).train()
+        m.load_state_dict(sd, strict=True)
+        calls.clear()
+        with torch.no_grad():
+            outs.append(m(torch.from_numpy(g["x"]), torch.from_numpy(g["t"]), None))
+        live = sum(isinstance(b.drop_path, mz.DropPath) for b in m.blocks[1:])     # rate 0 -> nn.Identity (blocks 0, 1)
+        assert live == cfg["depth"] - 2 and len(calls) == live + 1, (fused, len(calls))
+    assert rel_err(outs[0].numpy(), outs[1].numpy()) < 2e-5
+    m.eval()
+    calls.clear()
+    with torch.no_grad():
+        m(torch.from_numpy(g["x"]), torch.from_numpy(g["t"]), None)
+    assert rel_err(outs[0].numpy(), g["out"]) > 1e-2       # the mock really changes the result in train mode
 
 
 @pytest.mark.skipif(not os.path.isdir("/root/reference"), reason="needs the reference checkout (build container only)")

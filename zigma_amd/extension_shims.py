@@ -47,8 +47,9 @@ def selective_scan_cuda_bwd(u, delta, A, B, C, D_, z_, delta_bias_, dout, x_, ou
         _tok(u), _tok(delta), A.float().contiguous(), _tok(B[:, 0]), _tok(C[:, 0]),
         None if D_ is None else D_.float().contiguous(), _tok(z_), None if delta_bias_ is None else delta_bias_.float().contiguous(),
         _tok(dout), _tok(out_), bool(delta_softplus))
-    res = [du.transpose(1, 2), ddelta.transpose(1, 2), dA, dB.transpose(1, 2).unsqueeze(1), dC.transpose(1, 2).unsqueeze(1),
-           dD, dbias]
+    # dB / dC leave in the dtype of B / C like the reference's entry point (selective_scan.cpp:488)
+    res = [du.transpose(1, 2), ddelta.transpose(1, 2), dA, dB.transpose(1, 2).unsqueeze(1).to(B.dtype),
+           dC.transpose(1, 2).unsqueeze(1).to(C.dtype), dD, dbias]
     if z_ is not None:
         dz = dz.transpose(1, 2)
         if dz_ is not None:

@@ -92,7 +92,8 @@ def norm_bwd(xsum, weight, dy, dresidual_out, eps, is_rms, *, x_dtype, want_dx=T
         raise RuntimeError("dy must have the dtype of the normalised output")
     dx = dres = dw = db = None
     if weight is not None:
-        P.weight = _lib.ptr(weight.contiguous())
+        weight = weight.contiguous()          # kept alive in this local until after the launch
+        P.weight = _lib.ptr(weight)
         dw = torch.zeros(cols, device=xsum.device, dtype=torch.float32)
         P.dweight = _lib.ptr(dw)
     if has_bias:

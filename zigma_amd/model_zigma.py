@@ -25,6 +25,7 @@ import numpy as np
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
+import torch.utils.checkpoint
 from torch import Tensor
 
 from .attention import cross_attn, cross_attn_eligible
@@ -267,10 +268,10 @@ class Block(nn.Module):
     def forward(self, x: Tensor, residual: Optional[Tensor] = None, c=None, text=None, inference_params=None, skip=None):
         if self.skip_linear is not None:
             x = self.skip_linear(torch.cat([x, skip], dim=-1))
-        if self.training and not isinstance(self.drop_path, nn.Identity):
-            x = self.drop_path(x)
+        # stochastic depth exactly where the reference applies it (model_zigma.py:406-437): ONCE, on the incoming
+        # branch, and only when a residual stream already exists
         if not self.fused_add_norm:
-            residual = x if residual is None else residual + x
+            residual = x if residual is None else residual + self.drop_path(x)
             n = self.norm(residual.to(dtype=self.norm.weight.dtype))
             if self.residual_in_fp32:
                 residual = residual.to(torch.float32)
@@ -282,6 +283,8 @@ class Block(nn.Module):
             return h, residual
         if torch.is_grad_enabled() and (x.requires_grad or any(q.requires_grad for q in self.parameters())):
             return self.forward_train(x, residual, c, text)
+        if residual is not None:
+            x = self.drop_path(x)          # identity unless .train() with drop_path > 0 (under no_grad)
         pend, residual = self.forward_fused(Pending(x), residual, c, text)
         return pend.materialize(), residual
 
@@ -515,8 +518,12 @@ class ZigMa(nn.Module):
         residual = None
         # autograd recording -> the per-block differentiable composition (HIP forward + backward kernels);
         # otherwise (torch.no_grad(), the sampling path) the fully fused forward
-        needs_grad = torch.is_grad_enabled() and (hidden_states.requires_grad or c.requires_grad)
-        if self.fused_add_norm and not needs_grad and self.use_pe != 3:
+        # (any trainable parameter counts: with frozen embedders and trainable blocks neither hidden_states nor c
+        # requires grad, and the raw-launch fused path would silently cut the graph)
+        needs_grad = torch.is_grad_enabled() and (hidden_states.requires_grad or c.requires_grad
+                                                  or any(p.requires_grad for p in self.parameters()))
+        stochastic = self.training and not isinstance(self.drop_path, nn.Identity)   # per-block drop_path is live
+        if self.fused_add_norm and not needs_grad and not stochastic and self.use_pe != 3:
             pend = Pending(hidden_states.contiguous())
             mods, kvs = self._batched_conditioning(c, y)
             for i, block in enumerate(self.blocks):
@@ -529,7 +536,11 @@ class ZigMa(nn.Module):
             for layer_idx, block in enumerate(self.blocks):
                 if self.use_pe == 3:
                     hidden_states = hidden_states + self.pos_embed_list[layer_idx]
-                hidden_states, residual = block(hidden_states, residual=residual, c=c, text=y)
+                if self.use_checkpoint and needs_grad:      # activation checkpointing per block (reference :953-956)
+                    hidden_states, residual = torch.utils.checkpoint.checkpoint(
+                        self.ckpt_wrapper(block), hidden_states, residual, c, y, use_reentrant=False)
+                else:
+                    hidden_states, residual = block(hidden_states, residual=residual, c=c, text=y)
             if not self.fused_add_norm:
                 residual = hidden_states if residual is None else residual + self.drop_path(hidden_states)
                 hidden_states = self.norm_f(residual.to(dtype=self.norm_f.weight.dtype))
@@ -572,6 +583,11 @@ class ZigMa(nn.Module):
             kv_all = F.linear(text, Wkv).view(text.shape[0], text.shape[1], n, 2, inner)
             kvs = [(kv_all[:, :, i, 0], kv_all[:, :, i, 1]) for i in range(n)]
         return mods, kvs
+
+    def ckpt_wrapper(self, module):
+        def ckpt_forward(*inputs):
+            return module(*inputs)
+        return ckpt_forward
 
     def forward_with_cfg(self, x, t, y, cfg_scale):
         raise NotImplementedError

@@ -4,7 +4,8 @@ Mirrors the reference's `transport/integrators.py` class `ode` (:83-123).  The r
 the third-party `torchdiffeq.odeint` (not vendored, version unpinned, absent from this image), so the solver
 is restated here from its published algorithms — see `odeint` below.  Sampler-trajectory parity with
 torchdiffeq is therefore UNPINNED; the fixed-grid methods are checked against the CPU oracle and analytic
-solutions, dopri5 against analytic solutions and the fixed-grid limit.
+solutions, the adaptive ones against analytic solutions, the fixed-grid limit and an independent float64 numpy
+restatement of the same controller (oracle/zigma_oracle.py, tests/test_host_cpu.py).
 
 Solver state and arithmetic stay in the dtype of `x` (keep the latents fp32; the model casts at its own
 boundary), time points in float32 like the reference (`th.linspace`).
@@ -21,14 +22,18 @@ _DOPRI5 = dict(
     b=[35 / 384, 0.0, 500 / 1113, 125 / 192, -2187 / 6784, 11 / 84, 0.0],
     e=[35 / 384 - 1951 / 21600, 0.0, 500 / 1113 - 22642 / 50085, 125 / 192 - 451 / 720,
        -2187 / 6784 + 12231 / 42400, 11 / 84 - 649 / 6300, -1.0 / 60.0],
+    # dense output: y(t0 + h/2) = y0 + h * sum(mid_i k_i)  (Shampine's midpoint weights, torchdiffeq's DPS_C_MID)
+    mid=[6025192743 / 30085553152 / 2, 0.0, 51252292925 / 65400821598 / 2, -2691868925 / 45128329728 / 2,
+         187940372067 / 1594534317056 / 2, -1776094331 / 19743644256 / 2, 11237099 / 235043384 / 2],
     order=5, fsal=True)
 _BOSH3 = dict(
     c=[0.0, 1 / 2, 3 / 4, 1.0],
     a=[[], [1 / 2], [0.0, 3 / 4], [2 / 9, 1 / 3, 4 / 9]],
     b=[2 / 9, 1 / 3, 4 / 9, 0.0],
     e=[2 / 9 - 7 / 24, 1 / 3 - 1 / 4, 4 / 9 - 1 / 3, -1 / 8],
+    mid=None,
     order=3, fsal=True)
-_ADAPTIVE_HEUN = dict(c=[0.0, 1.0], a=[[], [1.0]], b=[0.5, 0.5], e=[0.5, -0.5], order=2, fsal=False)
+_ADAPTIVE_HEUN = dict(c=[0.0, 1.0], a=[[], [1.0]], b=[0.5, 0.5], e=[0.5, -0.5], mid=None, order=2, fsal=False)
 _ADAPTIVE = {"dopri5": _DOPRI5, "bosh3": _BOSH3, "adaptive_heun": _ADAPTIVE_HEUN}
 
 
@@ -58,70 +63,110 @@ def _fixed_step(method, f, t0, t1, x):
 FIXED_GRID = ("euler", "midpoint", "heun", "heun2", "heun3", "rk4")
 
 
-def _rms(v):
+def rms_norm(v):
+    """torchdiffeq's default norm: sqrt(mean(|v|^2)) over ALL elements (batch included), a 0-dim device tensor."""
     return v.float().pow(2).mean().sqrt()
 
 
-def _adaptive(tab, f, x, ts, rtol, atol, max_steps=100000):
-    """Embedded Runge-Kutta with the standard step controller (Hairer-Norsett-Wanner II.4): error norm =
-    RMS of err / (atol + rtol * max(|y0|, |y1|)); step factor 0.9 * ratio^(-1/order) clamped to [0.2, 10];
-    outputs at the requested times by cubic Hermite interpolation inside the accepted step."""
-    order, a, b, c, e = tab["order"], tab["a"], tab["b"], tab["c"], tab["e"]
-    t = float(ts[0])
-    t_end = float(ts[-1])
-    direction = 1.0 if t_end >= t else -1.0
-    f0 = f(ts[0], x)
-    # initial step (Hairer): h0 = 0.01 |y|/|f|, refined by one Euler probe
-    scale = atol + rtol * x.abs()
-    d0, d1 = float(_rms(x / scale)), float(_rms(f0 / scale))
-    h0 = 1e-6 if d0 < 1e-5 or d1 < 1e-5 else 0.01 * d0 / d1
-    f1 = f(ts[0] + direction * h0, x + direction * h0 * f0)
-    d2 = float(_rms((f1 - f0) / scale)) / h0
-    h1 = max(1e-6, h0 * 1e-3) if max(d1, d2) <= 1e-15 else (0.01 / max(d1, d2)) ** (1.0 / (order + 1))
-    h = direction * min(100 * h0, h1)
-    out = [x]
+class AdaptiveStats:
+    """Counters of the last adaptive solve (read by tests / tools; not part of the reference API)."""
+    nfe = 0
+    steps = 0
+    accepted = 0
+    host_reads = 0
+
+
+def _adaptive(tab, f, y0, ts, rtol, atol, norm=rms_norm, max_steps=100000):
+    """Embedded Runge-Kutta pair with torchdiffeq's controller (RKAdaptiveStepsizeODESolver; restated from the
+    published algorithm, the package is absent here):
+
+      * initial step by `_select_initial_step` with exponent 1 / order (torchdiffeq passes order - 1 and uses
+        1 / (order' + 1));
+      * error ratio = norm(err / (atol + rtol * max(|y0|, |y1|))), accepted iff <= 1;
+      * next step = dt * min(10, max(0.9 / ratio^(1/order), dfactor)) with dfactor = 0.2, but 1 when the step was
+        accepted with ratio < 1 (an accepted step never shrinks), and dt * 10 when ratio == 0;
+      * steps are NOT clamped to the output times or to the end point: the solver steps until t1 >= the requested
+        time and evaluates the 4th-order dense output fitted through (y0, y_mid, y1, f0, f1) there (dopri5: Shampine's
+        mid-point weights; bosh3 / adaptive_heun: y_mid from the cubic Hermite interpolant, so the fit IS that cubic —
+        torchdiffeq's own mid-point weights for these two low-order pairs could not be checked here).
+
+    Step control runs ON THE DEVICE: error norm, step factor, accepted/rejected selection of (y, f, t) and the step
+    size are 0-dim device tensors; the host reads ONE small tensor (accepted?, t1) per step, which it needs to know
+    which output times the step covered and when to stop.  Time is float64 like torchdiffeq's; the model sees float32."""
+    order, a, b, c, e, mid = tab["order"], tab["a"], tab["b"], tab["c"], tab["e"], tab["mid"]
+    dev = y0.device
+    f64 = dict(device=dev, dtype=th.float64)
+    ts_host = [float(v) for v in ts.tolist()]                        # output times are host data to begin with
+    if any(t1 <= t0 for t0, t1 in zip(ts_host, ts_host[1:])):
+        raise ValueError("t must be strictly increasing")
+    call = lambda t, y: f(t.to(th.float32), y)
+    t0 = th.tensor(ts_host[0], **f64)
+    f0 = call(t0, y0)
+    # -- _select_initial_step, all on the device --------------------------------------------------------
+    scale = atol + y0.abs() * rtol
+    d0, d1 = norm(y0 / scale).double(), norm(f0 / scale).double()
+    h0 = th.where((d0 < 1e-5) | (d1 < 1e-5), th.full((), 1e-6, **f64), 0.01 * d0 / d1.clamp_min(1e-300))
+    f1 = call(t0 + h0, y0 + h0 * f0)
+    d2 = norm((f1 - f0) / scale).double() / h0
+    dmax = th.maximum(d1, d2)
+    h1 = th.where(dmax <= 1e-15, th.clamp_min(h0 * 1e-3, 1e-6), (0.01 / dmax.clamp_min(1e-300)) ** (1.0 / order))
+    dt = th.minimum(100 * h0, h1)
+    st = AdaptiveStats
+    st.nfe, st.steps, st.accepted, st.host_reads = 2, 0, 0, 0
+    out = [y0]
     nxt = 1
-    nfe = 2
-    for _ in range(max_steps):
-        if nxt >= len(ts):
-            break
-        if (t + h - t_end) * direction > 0:
-            h = t_end - t
+    t0_host = ts_host[0]
+    y = y0
+    ten, one, fifth = th.full((), 10.0, **f64), th.full((), 1.0, **f64), th.full((), 0.2, **f64)
+    while nxt < len(ts_host):
+        if st.steps >= max_steps:
+            raise RuntimeError("adaptive ODE solver exceeded max_steps")
+        st.steps += 1
         ks = [f0]
         for i in range(1, len(c)):
-            xi = x
+            yi = y
             for j, aij in enumerate(a[i]):
                 if aij != 0.0:
-                    xi = xi + (h * aij) * ks[j]
-            ks.append(f(x.new_tensor(t + c[i] * h, dtype=th.float32), xi))
-        nfe += len(c) - 1
-        x1 = x
-        err = th.zeros_like(x)
-        for bi, ei, k in zip(b, e, ks):
+                    yi = yi + (dt * aij) * ks[j]
+            ks.append(call(t0 + c[i] * dt, yi))
+        st.nfe += len(c) - 1
+        y1, err, y_mid = y, None, y
+        for bi, ei, mi, k in zip(b, e, mid or [0.0] * len(b), ks):
             if bi != 0.0:
-                x1 = x1 + (h * bi) * k
+                y1 = y1 + (dt * bi) * k
             if ei != 0.0:
-                err = err + (h * ei) * k
-        tol = atol + rtol * th.maximum(x.abs(), x1.abs())
-        ratio = float(_rms(err / tol))
-        if ratio <= 1.0:
-            f_new = ks[-1] if tab["fsal"] else f(x.new_tensor(t + h, dtype=th.float32), x1)
-            nfe += 0 if tab["fsal"] else 1
-            while nxt < len(ts) and (float(ts[nxt]) - (t + h)) * direction <= 1e-12:
-                s = (float(ts[nxt]) - t) / h                # cubic Hermite on [t, t + h]
-                h00, h10 = 2 * s ** 3 - 3 * s ** 2 + 1, s ** 3 - 2 * s ** 2 + s
-                h01, h11 = -2 * s ** 3 + 3 * s ** 2, s ** 3 - s ** 2
-                out.append(x1 if abs(s - 1.0) < 1e-12 else h00 * x + (h10 * h) * f0 + h01 * x1 + (h11 * h) * f_new)
-                nxt += 1
-            t, x, f0 = t + h, x1, f_new
-        factor = 10.0 if ratio == 0.0 else min(10.0, max(0.2, 0.9 * ratio ** (-1.0 / order)))
-        h = h * factor
-    else:
-        raise RuntimeError("adaptive ODE solver exceeded max_steps")
-    return th.stack(out), nfe
+                err = (dt * ei) * k if err is None else err + (dt * ei) * k
+            if mi != 0.0:
+                y_mid = y_mid + (dt * mi) * k
+        ratio = norm(err / (atol + rtol * th.maximum(y.abs(), y1.abs()))).double()
+        accept = ratio <= 1
+        dfac = th.where(ratio < 1, one, fifth)
+        factor = th.where(ratio == 0, ten, th.minimum(ten, th.maximum(0.9 / ratio.clamp_min(1e-300) ** (1.0 / order), dfac)))
+        t1 = t0 + dt
+        flag, t1_host = th.stack([accept.double(), t1]).tolist()      # the ONE host read of this step
+        st.host_reads += 1
+        if flag:
+            st.accepted += 1
+            f_new = ks[-1] if tab["fsal"] else call(t1, y1)
+            st.nfe += 0 if tab["fsal"] else 1
+            if nxt < len(ts_host) and ts_host[nxt] <= t1_host:
+                # dense output (torchdiffeq _interp_fit / _interp_evaluate): quartic through y0, y_mid, y1, f0, f1
+                if mid is None:       # no dense-output weights: the value the cubic Hermite interpolant takes at t0 + dt/2
+                    y_mid = 0.5 * (y + y1) + (dt * 0.125) * (f0 - f_new)
+                ca = 2 * dt * (f_new - f0) - 8 * (y1 + y) + 16 * y_mid
+                cb = dt * (5 * f0 - 3 * f_new) + 18 * y + 14 * y1 - 32 * y_mid
+                cc = dt * (f_new - 4 * f0) - 11 * y - 5 * y1 + 16 * y_mid
+                cd = dt * f0
+                while nxt < len(ts_host) and ts_host[nxt] <= t1_host:
+                    s = (ts_host[nxt] - t0_host) / (t1_host - t0_host)
+                    out.append((y + s * cd + s ** 2 * cc + s ** 3 * cb + s ** 4 * ca).to(y0.dtype))
+                    nxt += 1
+            y, f0, t0, t0_host = y1, f_new, t1, t1_host
+        dt = dt * factor
+    return th.stack(out), st.nfe
 
 
-def odeint(func, y0, t, *, method="dopri5", rtol=1e-3, atol=1e-6):
+def odeint(func, y0, t, *, method="dopri5", rtol=1e-3, atol=1e-6, norm=rms_norm):
     """Solve y' = func(t, y), y(t[0]) = y0; returns the solution at every t[i], shape (len(t), *y0.shape).
     Fixed-grid methods step exactly on the grid `t`; adaptive ones only report there."""
     rtol = rtol[0] if isinstance(rtol, (list, tuple)) else rtol
@@ -134,7 +179,7 @@ def odeint(func, y0, t, *, method="dopri5", rtol=1e-3, atol=1e-6):
             ys.append(y)
         return th.stack(ys)
     if method in _ADAPTIVE:
-        return _adaptive(_ADAPTIVE[method], func, y0, t, rtol, atol)[0]
+        return _adaptive(_ADAPTIVE[method], func, y0, t, rtol, atol, norm=norm)[0]
     raise ValueError(f"sampling_method {method!r} is not implemented (have {FIXED_GRID + tuple(_ADAPTIVE)})")
 
 
@@ -229,5 +274,9 @@ class ode:
         def _fn_tuple(t, y):
             return pack(self.drift(unpack(y), ones * t, model, **model_kwargs))
 
-        ys = odeint(_fn_tuple, pack(x), t, method=self.sampler_type, atol=[self.atol], rtol=[self.rtol])
+        def mixed_norm(v):        # torchdiffeq's default for tuple states: max over the components' RMS norms
+            parts = th.split(v, sizes, dim=1)
+            return th.stack([rms_norm(q) for q in parts]).max()
+
+        ys = odeint(_fn_tuple, pack(x), t, method=self.sampler_type, atol=[self.atol], rtol=[self.rtol], norm=mixed_norm)
         return tuple(q.reshape((ys.shape[0],) + tuple(sh)) for q, sh in zip(th.split(ys, sizes, dim=2), shapes))
