@@ -14,8 +14,17 @@ N > 1   = batch-sharded replicas (weak scaling: B=64 per rank); the path has no 
           (the analogue of accelerator.gather in sample_acc.py:435), which is inside the timed region.
 roofline  : the fused zigzag selective-scan kernel, timed with HIP events around every launch of it
             inside the timed steps; achieved = algorithmic bytes / mean launch time.
-cpu_baseline : the numpy oracle (oracle/zigma_oracle.py, a port of the reference's pure-torch path) run on the
-            host cores on a bounded sample (one forward of the same model at B=2), rank 0, N=1 only.
+            `frac` is the HBM-roofline fraction the metric asks for; the kernel itself is VALU-issue limited
+            (DESIGN.md §3.1), so the line also carries `valu_frac` = the recurrence's VALU floor at the guide's issue
+            rates (4 plain ops x 2 cycles + 1 v_exp_f32 x 8 cycles per (element, state) wave-instruction group)
+            divided by the measured launch time.  `traffic` is NOT measured in this run: it is the per-launch HBM
+            byte count of the committed rocprofv3 PMC passes and is labelled with the file it came from.
+cpu_baseline : the reference's OWN CPU path — its unmodified `ZigMa.forward` over `selective_scan_ref` /
+            `causal_conv1d_ref` (oracle/ref_shim.py; from /root/reference, or on the GPU box from oracle/_ref/, the
+            same modules compiled to bytecode by oracle/build_ref.py) — on the host cores, bounded sample (forwards of
+            the same model at B=2), rank 0, N=1 only; `kind: "reference"`.  Falls back to the numpy port (`kind: "port"`)
+            only when neither is importable.
+N > 1 without a launcher: `python bench.py --gpus N` re-executes itself under torch.distributed.run with N ranks.
 """
 import argparse
 import json
@@ -29,6 +38,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK = 8.0e12        # B/s, MI355X HBM3E spec (MI355X_MICROARCH.md)
+SCLK = 2.4e9             # Hz, max shader clock (MI355X_MICROARCH.md)
 
 WORKLOADS = {
     # BASELINE configs[1]: README model, bf16, B=64 on one MI355X
@@ -69,14 +79,14 @@ def pmc_traffic():
     """HBM bytes per scan launch from the committed rocprofv3 PMC passes (profiles/*pmc_scan*.json written by
     tools/pmc_scan.sh; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950), or None."""
     import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_scan*.json")))
+    files = sorted(f for f in glob.glob(os.path.join(ROOT, "profiles", "*pmc_scan*.json")) if "bwd" not in f)
     if not files:
-        return None
+        return None, None
     try:
         d = json.load(open(files[-1]))
-        return d.get("hbm_bytes_per_launch")
+        return d.get("hbm_bytes_per_launch"), "profiles/" + os.path.basename(files[-1])
     except Exception:
-        return None
+        return None, None
 
 
 def build_model(cfg, device, dtype, seed=0):
@@ -102,8 +112,75 @@ def make_inputs(wl, batch, device, seed):
     return x, t, y
 
 
-def cpu_baseline(wl, seed=0):
-    """Oracle forward (numpy, fp32) of the same architecture at B=2 on the host cores."""
+def _host_threads():
+    try:
+        return len(os.sched_getaffinity(0))
+    except Exception:
+        return os.cpu_count() or 1
+
+
+def _cpu_model():
+    try:
+        for ln in open("/proc/cpuinfo"):
+            if ln.startswith("model name"):
+                return ln.split(":", 1)[1].strip()
+    except Exception:
+        pass
+    return "unknown"
+
+
+def cpu_baseline_reference(wl, seed=0, budget_s=20.0):
+    """The reference's own pure-CPU path on the host cores: the unmodified ZigMa.forward through
+    oracle/ref_shim.py (selective_scan_ref, selective_scan_interface.py:86-152, is ~90 % of it), B=2, fp32, as many
+    forwards as fit in `budget_s` (at least one); plus selective_scan_ref alone at the layer's shape."""
+    import contextlib
+    import io
+    from oracle import ref_shim
+    threads = _host_threads()
+    torch.set_num_threads(threads)
+    with contextlib.redirect_stdout(io.StringIO()):           # the reference prints its tables while it builds
+        mz, ssi, _, _ = ref_shim.reference_modules()
+        torch.manual_seed(seed)
+        m = mz.ZigMa(device="cpu", **wl["model"]).eval()
+    g = torch.Generator().manual_seed(seed)
+    with torch.no_grad():
+        for blk in m.blocks:                                  # non-zero gates, as on the GPU side
+            b = blk.adaLN_modulation[-1].bias
+            b.copy_(torch.randn(b.shape, generator=g) * 0.5)
+    B = 2
+    L = (wl["model"]["img_dim"] // wl["model"]["patch_size"]) ** 2
+    x = torch.randn((B,) + wl["x"], generator=g)
+    t = torch.rand(B, generator=g)
+    y = torch.rand((B,) + wl["y"][1:], generator=g)
+    n, t0 = 0, time.perf_counter()
+    with torch.no_grad():
+        while n == 0 or (time.perf_counter() - t0) * (n + 1) / n < budget_s:
+            m(x, t, y)
+            n += 1
+    dt = (time.perf_counter() - t0) / n
+    # selective_scan_ref alone, the shape one layer sees at B=2 (u, delta, z: (B, Di, L); B, C: (B, N, L))
+    Di, N = 2 * wl["model"]["embed_dim"], 16
+    u, dl, z = (torch.randn(B, Di, L, generator=g) for _ in range(3))
+    A = -torch.rand(Di, N, generator=g)
+    Bm, Cm = torch.randn(B, N, L, generator=g), torch.randn(B, N, L, generator=g)
+    D, db = torch.randn(Di, generator=g), torch.rand(Di, generator=g)
+    with torch.no_grad():
+        ssi.selective_scan_ref(u, dl, A, Bm, Cm, D, z, db, True)
+        s0 = time.perf_counter()
+        ssi.selective_scan_ref(u, dl, A, Bm, Cm, D, z, db, True)
+        sdt = time.perf_counter() - s0
+    scan_bytes = B * L * (4 * 4 * Di + 2 * 4 * N) + 4 * Di * (N + 2)          # fp32 I/O
+    src = "/root/reference" if os.path.isdir("/root/reference") else "oracle/_ref (bytecode of the reference, oracle/build_ref.py)"
+    return dict(value=B * L / dt, unit="tokens/s", cores=threads, kind="reference", cpu=_cpu_model(),
+                sample=f"{n} forward(s) of the reference's own ZigMa (E=640, depth=18, has_text; selective_scan_ref + "
+                       f"causal_conv1d_ref via oracle/ref_shim.py, from {src}) at B={B}, fp32, torch "
+                       f"{torch.__version__.split('+')[0]} CPU, {threads} threads, {dt:.1f} s per forward",
+                selective_scan_ref=dict(tokens_per_s=B * L / sdt, GBps=scan_bytes / sdt / 1e9, seconds=sdt,
+                                        shape=f"B={B}, Di={Di}, L={L}, N={N}, fp32"))
+
+
+def cpu_baseline_port(wl, seed=0):
+    """Fallback: the numpy oracle's forward of the same architecture at B=2 (only when the reference is not importable)."""
     import numpy as np
     from oracle import zigma_oracle as zo
     try:
@@ -128,8 +205,35 @@ def cpu_baseline(wl, seed=0):
     om.forward(x, t, y)
     dt = time.perf_counter() - t0
     L = (wl["model"]["img_dim"] // wl["model"]["patch_size"]) ** 2
-    return dict(value=B * L / dt, unit="tokens/s", cores=threads, kind="port",
+    return dict(value=B * L / dt, unit="tokens/s", cores=threads, kind="port", cpu=_cpu_model(),
                 sample=f"1 forward of the same model (E=640, depth=18, has_text) at B={B}, fp32 numpy oracle, {dt:.1f} s")
+
+
+def cpu_baseline(wl):
+    from oracle import build_ref
+    if build_ref.available():
+        try:
+            return cpu_baseline_reference(wl)
+        except Exception as e:          # report, then fall back to the port rather than lose the bench line
+            print(f"bench.py: reference CPU baseline failed ({type(e).__name__}: {e}); timing the numpy port", file=sys.stderr)
+    return cpu_baseline_port(wl)
+
+
+def respawn_under_launcher(n):
+    """`python bench.py --gpus N` with no launcher around it: become `python -m torch.distributed.run ... bench.py ...`
+    (one rank per GPU, rendezvous on 127.0.0.1) — the analogue of `accelerate launch` in the reference (README.md:165)."""
+    import socket
+    have = torch.cuda.device_count()
+    if have < n:
+        raise SystemExit(f"bench.py: --gpus {n} but only {have} GPU(s) are visible; refusing to report a smaller job")
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    sys.stdout.flush()
+    os.execv(sys.executable, cmd)
 
 
 def main():
@@ -146,12 +250,14 @@ def main():
     from zigma_amd import sharded_sampling as ss
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        respawn_under_launcher(args.gpus)                 # does not return
     local_rank = int(os.environ.get("LOCAL_RANK", 0))
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     rank, world, _ = ss.init_from_env(backend="nccl", device=device)
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the job has WORLD_SIZE={world}")
     dist = None
     if world > 1:
         import torch.distributed as dist
@@ -186,9 +292,16 @@ def main():
         if timer.pairs:
             ms = timer.mean_ms()
             ach = algo_bytes / (ms * 1e-3)
+            traffic, traffic_src = pmc_traffic()
+            # VALU floor of the recurrence at the guide's issue rates (MI355X_MICROARCH.md: v_fma_f32 2 cycles per wave64
+            # instruction per SIMD, transcendental quarter rate = 8): 4 plain + 1 exp per (element, state), 1024 SIMDs
+            groups = batch * L * Di * N / 64
+            valu_floor_us = groups * (4 * 2 + 8) / (1024 * SCLK) * 1e6
             roof = dict(bound="hbm", kernel="scan_tok (fused zigzag selective scan)", achieved=ach / 1e9,
-                        peak=HBM_PEAK / 1e9, unit="GB/s", frac=ach / HBM_PEAK, traffic=pmc_traffic(),
-                        launch_us=ms * 1e3, launches=len(timer.pairs), algorithmic_bytes=algo_bytes)
+                        peak=HBM_PEAK / 1e9, unit="GB/s", frac=ach / HBM_PEAK, traffic=traffic,
+                        traffic_source=traffic_src, launch_us=ms * 1e3, launches=len(timer.pairs),
+                        algorithmic_bytes=algo_bytes, limiter="valu", valu_floor_us=valu_floor_us,
+                        valu_frac=valu_floor_us / (ms * 1e3))
         line = dict(metric="denoiser-forward latents/sec (BxL tokens/s), ZigMa d=640 L=32^2",
                     value=world * batch * L * args.steps / elapsed, unit="tokens/s", n_gpus=world, steps=args.steps,
                     warmup=args.warmup, ms_per_step=elapsed / args.steps * 1e3, higher_is_better=True, scaling="weak",

@@ -1,9 +1,10 @@
 """Import shims that let the UNMODIFIED reference (/root/reference) run on CPU.
 
 TEST INFRASTRUCTURE ONLY.  Used by oracle/make_golden.py (in the build container,
-where /root/reference exists) to generate the golden fixtures under tests/golden/.
-Nothing in the product path imports this file, and nothing here is available on the
-GPU box (there is no /root/reference there).
+where /root/reference exists) to generate the golden fixtures under tests/golden/, and by
+bench.py's `cpu_baseline` leg to time the reference's own CPU path.  Nothing in the product
+path imports this file.  On the GPU box there is no /root/reference: the same modules are then
+imported from oracle/_ref/ (bytecode compiled from the reference by oracle/build_ref.py).
 
 Recipe = SURVEY.md §8c:
   1. stand-in modules `causal_conv1d_cuda` / `selective_scan_cuda` backed by the
@@ -26,7 +27,11 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+import os
+
 REF = "/root/reference"
+if not os.path.isdir(REF):            # the GPU box: the reference's hot-path modules as bytecode (oracle/build_ref.py)
+    REF = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_ref")
 _installed = False
 
 

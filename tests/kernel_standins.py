@@ -11,13 +11,27 @@ def _np(t):
     return None if t is None else t.detach().float().cpu().numpy()
 
 
+def _split(a, period):
+    """(B, D, n * period) -> (B * n, D, period): the independent sequences a reset_period concatenates along seqlen."""
+    Bn, D, Lt = a.shape
+    return a.reshape(Bn, D, Lt // period, period).transpose(0, 2, 1, 3).reshape(-1, D, period)
+
+
+def _join(a, Bn, period):
+    D = a.shape[1]
+    return a.reshape(Bn, -1, D, period).transpose(0, 2, 1, 3).reshape(Bn, D, -1)
+
+
 def conv_raw(x, weight, bias, silu, *, out=None, x_row_index=None, reset_period=0):
-    assert not reset_period, "stand-in: reset_period is exercised on the GPU only"
     xs = _np(x)
     if x_row_index is not None:
         xs = xs[:, :, x_row_index.long().cpu().numpy()]
-    y = zo.causal_conv1d(xs, _np(weight), _np(bias), "silu" if silu else None)
-    y = torch.from_numpy(y).to(x.dtype)
+    if reset_period:
+        y = _join(zo.causal_conv1d(_split(xs, reset_period), _np(weight), _np(bias), "silu" if silu else None),
+                  xs.shape[0], reset_period)
+    else:
+        y = zo.causal_conv1d(xs, _np(weight), _np(bias), "silu" if silu else None)
+    y = torch.from_numpy(np.ascontiguousarray(y)).to(x.dtype)
     if out is None:
         out = torch.empty_like(x)
     out.copy_(y)
@@ -27,12 +41,20 @@ def conv_raw(x, weight, bias, silu, *, out=None, x_row_index=None, reset_period=
 def scan_raw(u, delta, A, B, C, D=None, z=None, delta_bias=None, delta_softplus=False, *, out=None, out_z=None,
              x=None, z_row_index=None, out_row_index=None, want_out=True, checkpoints=None, reset_period=0,
              chunk_len=2048):
-    assert not reset_period and checkpoints is None, "stand-in: GPU-only features"
+    assert checkpoints is None, "stand-in: GPU-only feature"
     zs = _np(z)
     if zs is not None and z_row_index is not None:
         zs = zs[:, :, z_row_index.long().cpu().numpy()]
-    y, last = zo.selective_scan(_np(u), _np(delta), _np(A), _np(B), _np(C), _np(D), None, _np(delta_bias), delta_softplus,
-                                return_last_state=True)
+    if reset_period:                                  # independent sequences of reset_period steps along seqlen
+        Bn, P = u.shape[0], reset_period
+        bc = lambda M: _split(_np(M)[:, 0], P)[:, None]                     # (B, 1, N, L) -> (B * n, 1, N, P)
+        y, last = zo.selective_scan(_split(_np(u), P), _split(_np(delta), P), _np(A), bc(B), bc(C), _np(D), None,
+                                    _np(delta_bias), delta_softplus, return_last_state=True)
+        y = np.ascontiguousarray(_join(y, Bn, P))
+        assert x is None
+    else:
+        y, last = zo.selective_scan(_np(u), _np(delta), _np(A), _np(B), _np(C), _np(D), None, _np(delta_bias), delta_softplus,
+                                    return_last_state=True)
     yz = y * zo.silu(zs) if zs is not None else None
 
     def place(arr):

@@ -257,6 +257,39 @@ def test_module_plumbing_with_oracle_standins(name, monkeypatch):
     assert rel_err(out.numpy(), g["out"]) < 2e-5, rel_err(out.numpy(), g["out"])
 
 
+def test_video16_no_copy_temporal_path_host_logic(monkeypatch):
+    """16-frame model: the temporal layers take the no-copy arrangement (batch = k, sequence = (b, t) on strided views,
+    tiled time tables, reset_period = T).  Host logic with oracle-backed stand-ins against the REFERENCE's output
+    (tests/golden/r2_small_video16.npz, oracle/make_golden_r2.py; weights regenerated by oracle/param_fill.py)."""
+    import kernel_standins
+    import zigma_amd.mamba_simple as ms
+    from oracle.param_fill import fill_state
+    from zigma_amd.model_zigma import ZigMa
+    kernel_standins.install(monkeypatch)
+    resets = []
+    real = ms.mamba_inner_tok
+    monkeypatch.setattr(ms, "mamba_inner_tok", lambda *a, **k: (resets.append(k.get("reset_period", 0)), real(*a, **k))[1])
+    g = load_golden("r2_small_video16.npz")
+    cfg = ast.literal_eval(str(g["cfg"]))
+    m = fill_state(ZigMa(device="cpu", **cfg), int(g["seed"])).eval()
+    with torch.no_grad():
+        out = m(torch.from_numpy(g["x"]), torch.from_numpy(g["t"]), torch.from_numpy(g["y"]))
+    assert resets.count(16) == 2 and resets.count(0) == 4            # s s t s s t
+    assert rel_err(out.numpy(), g["out"]) < 2e-5, rel_err(out.numpy(), g["out"])
+
+
+def test_oracle_model_vs_r2_reference_goldens():
+    """the numpy oracle against the round-2 reference outputs (16-frame video model; param_fill weights)."""
+    from oracle.param_fill import fill_state
+    from zigma_amd.model_zigma import ZigMa
+    g = load_golden("r2_small_video16.npz")
+    cfg = ast.literal_eval(str(g["cfg"]))
+    m = fill_state(ZigMa(device="cpu", **cfg), int(g["seed"]))
+    om = zo.ZigMaOracle({k: v.numpy() for k, v in m.state_dict().items()}, cfg)
+    out = om.forward(g["x"], g["t"], g["y"])
+    assert rel_err(out, g["out"]) < 2e-5, rel_err(out, g["out"])
+
+
 def test_drop_path_is_applied_once_per_block_in_train_mode(monkeypatch):
     """Stochastic depth (reference model_zigma.py:406-437,963-975): once per block on the incoming branch when a residual
     stream exists, once before the final norm.  DropPath is mocked to the deterministic x -> 2x so a double application
