@@ -136,7 +136,7 @@ def cpu_baseline_reference(wl, seed=0, budget_s=20.0):
     import contextlib
     import io
     from oracle import ref_shim
-    threads = _host_threads()
+    threads = min(_host_threads(), 32)            # torch's CPU kernels stop scaling (and start spinning) long before 128
     torch.set_num_threads(threads)
     with contextlib.redirect_stdout(io.StringIO()):           # the reference prints its tables while it builds
         mz, ssi, _, _ = ref_shim.reference_modules()
@@ -209,14 +209,23 @@ def cpu_baseline_port(wl, seed=0):
                 sample=f"1 forward of the same model (E=640, depth=18, has_text) at B={B}, fp32 numpy oracle, {dt:.1f} s")
 
 
-def cpu_baseline(wl):
+def cpu_baseline(wl, name, limit_s=240):
+    """Runs in a CHILD process with a hard time limit (a host with many cores and a small CPU quota can make the torch CPU
+    path crawl; the GPU numbers of the line must not depend on it)."""
+    import subprocess
     from oracle import build_ref
-    if build_ref.available():
+    for kind in (["reference"] if build_ref.available() else []) + ["port"]:
         try:
-            return cpu_baseline_reference(wl)
-        except Exception as e:          # report, then fall back to the port rather than lose the bench line
-            print(f"bench.py: reference CPU baseline failed ({type(e).__name__}: {e}); timing the numpy port", file=sys.stderr)
-    return cpu_baseline_port(wl)
+            r = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-baseline-only", kind, "--workload", name],
+                               capture_output=True, text=True, timeout=limit_s,
+                               env=dict(os.environ, HIP_VISIBLE_DEVICES="", ROCR_VISIBLE_DEVICES=""))
+            lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+            if r.returncode == 0 and lines:
+                return json.loads(lines[-1])
+            print(f"bench.py: {kind} CPU baseline failed (rc {r.returncode}): {r.stderr[-300:]}", file=sys.stderr)
+        except subprocess.TimeoutExpired:
+            print(f"bench.py: {kind} CPU baseline exceeded {limit_s} s on this host; trying the next kind", file=sys.stderr)
+    return None
 
 
 def respawn_under_launcher(n):
@@ -245,7 +254,12 @@ def main():
     ap.add_argument("--batch", type=int, default=None, help="per-GPU batch (default: the workload's)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-scan-events", action="store_true")
+    ap.add_argument("--cpu-baseline-only", default=None, help=argparse.SUPPRESS)      # child-process leg of cpu_baseline()
     args = ap.parse_args()
+    if args.cpu_baseline_only:
+        fn = cpu_baseline_reference if args.cpu_baseline_only == "reference" else cpu_baseline_port
+        print(json.dumps(fn(WORKLOADS[args.workload])), flush=True)
+        return
 
     from zigma_amd import sharded_sampling as ss
     if not torch.cuda.is_available():
@@ -311,7 +325,7 @@ def main():
                                 global_batch=world * batch, seq_len=L, parallelism=f"batch-sharded x{world}"),
                     roofline=roof)
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(wl)
+            line["cpu_baseline"] = cpu_baseline(wl, args.workload)
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()

@@ -44,9 +44,9 @@ def _r2_model(name, dtype):
     from zigma_amd.model_zigma import ZigMa
     g = load_golden(name + ".npz")
     cfg = ast.literal_eval(str(g["cfg"]))
-    m = ZigMa(device="cpu", dtype=torch.float32, **cfg)
+    m = ZigMa(device="cpu", dtype=dtype, **cfg)     # (constructed IN the dtype, like the reference run: model_zigma.py:575)
     fill_state(m, int(g["seed"]))                   # same numpy stream as the reference run (sorted state_dict keys)
-    m = m.to(DEV).to(dtype).eval()
+    m = m.to(DEV).eval()
     y = g.get("y")
     if y is not None:
         y = torch.from_numpy(y).to(DEV)
