@@ -10,7 +10,9 @@
  * Conventions (all entry points):
  *   - plain pointers and sizes only; every pointer is a DEVICE pointer on the current device;
  *   - the caller owns all memory and allocates the outputs; the library never allocates,
- *     never synchronises, keeps no global state and is re-entrant;
+ *     never synchronises, keeps no state a caller depends on and is re-entrant (which kernel variant served a
+ *     call is reported through the parameter block's optional `info` out-field; zigma_last_kernel() is a
+ *     thread-local DIAGNOSTIC for tests and logs only);
  *   - `stream` is a hipStream_t passed as void*; one call = one or more kernel launches on it;
  *   - strides are in ELEMENTS of the tensor's own dtype;
  *   - returns ZIGMA_OK (0) or a negative zigma_status_t; zigma_strerror() names it.  The Python
@@ -25,7 +27,16 @@
 extern "C" {
 #endif
 
-#define ZIGMA_ABI_VERSION 2   /* 2: parameter blocks grew (row tables in the backward, checkpoints, reset_period) */
+#define ZIGMA_ABI_VERSION 3   /* 2: parameter blocks grew (row tables in the backward, checkpoints, reset_period)
+                               * 3: scan block: `info` out-field, ZIGMA_SCAN_Z_PREACTIVATED flag */
+
+/* zigma_scan_params_t.flags */
+#define ZIGMA_SCAN_Z_PREACTIVATED 2   /* z already holds silu(z) (the in_proj GEMM epilogue applied it): out_z = y * z */
+
+/* zigma_scan_params_t.info[0]: which kernel family served the call */
+#define ZIGMA_SCAN_KERNEL_GENERIC 1
+#define ZIGMA_SCAN_KERNEL_TOK 2    /* scan_tok_kernel: token-major, all features (carries, checkpoints, reset_period) */
+#define ZIGMA_SCAN_KERNEL_TOK2 3   /* scan_tok2_kernel: token-major hot kernel (16-bit I/O, dstate 16, gate only)      */
 
 typedef enum zigma_status {
     ZIGMA_OK = 0,
@@ -68,7 +79,7 @@ typedef struct zigma_scan_params {
     int32_t io_dtype;   /* zigma_dtype_t of u, delta, z, out, out_z                                */
     int32_t bc_dtype;   /* zigma_dtype_t of VARIABLE B / C (reference: == io_dtype)               */
     int32_t chunk_len;  /* carry spacing for x; 0 -> 2048 (reference: selective_scan.cpp:307)      */
-    int32_t flags;      /* reserved, must be 0                                                      */
+    int32_t flags;      /* 0 or ZIGMA_SCAN_Z_PREACTIVATED (other bits reserved, must be 0)          */
 
     int64_t u_batch_stride, u_d_stride, u_l_stride;
     int64_t delta_batch_stride, delta_d_stride, delta_l_stride;
@@ -91,13 +102,16 @@ typedef struct zigma_scan_params {
     /* optional float32 [batch][dim/64][ceil(seqlen/16)][dstate][64]: the state h BEFORE every 16-step tile, written by the
      * token-major kernel when both out and out_z are requested (the training forward); zigma_selective_scan_bwd takes it
      * back as `checkpoints` and skips its own forward phase.  Ignored (left untouched) by every other kernel variant:
-     * check zigma_last_kernel() == "scan_tok_n16" / "scan_tok_n8" before trusting it. */
+     * pass `info` and check info[1] == 1 before trusting it. */
     float *checkpoints;
     /* > 0: the sequence is a concatenation of independent sequences of this many steps (a multiple of 16): the state is
      * reset to 0 at every multiple.  Lets the video temporal layers (b (t k) c tokens, scan over t for every (b, k)) run as
      * batch = k, seqlen = b * t on strided views with no transposing copy.  Token-major kernel only; x must be NULL. */
     int32_t reset_period;
     int32_t pad2_;
+    /* optional HOST pointer to int32[2], written by the call before it returns (never by a kernel):
+     * info[0] = ZIGMA_SCAN_KERNEL_* that was launched, info[1] = 1 iff `checkpoints` is being written. */
+    int32_t *info;
 } zigma_scan_params_t;
 
 int zigma_selective_scan_fwd(const zigma_scan_params_t *p, void *stream);

@@ -40,8 +40,10 @@ def conv_raw(x, weight, bias, silu, *, out=None, x_row_index=None, reset_period=
 
 def scan_raw(u, delta, A, B, C, D=None, z=None, delta_bias=None, delta_softplus=False, *, out=None, out_z=None,
              x=None, z_row_index=None, out_row_index=None, want_out=True, checkpoints=None, reset_period=0,
-             chunk_len=2048):
-    assert checkpoints is None, "stand-in: GPU-only feature"
+             chunk_len=2048, z_preactivated=False, info=None):
+    assert checkpoints is None and not z_preactivated, "stand-in: GPU-only features"
+    if info is not None:
+        info[:] = [2, 0]
     zs = _np(z)
     if zs is not None and z_row_index is not None:
         zs = zs[:, :, z_row_index.long().cpu().numpy()]

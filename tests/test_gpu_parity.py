@@ -92,7 +92,7 @@ def _tok_case(Bsz, L, Di, Nst, dtype, has_z, use_perm, seed, real_A=False):
     return dict(u=u, delta=delta, xdbl=xdbl, zfull=zfull, A=A, D=D, db=db, perm=perm, R=R, N=Nst, has_z=has_z)
 
 
-def _run_tok(c, dtype, want_x=False):
+def _run_tok(c, dtype, want_x=False, **extra):
     from zigma_amd.selective_scan_interface import scan_raw
     R, Nst = c["R"], c["N"]
     u, delta, xdbl, zfull = T(c["u"], dtype), T(c["delta"], dtype), T(c["xdbl"], dtype), T(c["zfull"], dtype)
@@ -104,7 +104,7 @@ def _run_tok(c, dtype, want_x=False):
     kw = dict(out_z=y.transpose(1, 2)) if c["has_z"] else dict(out=y.transpose(1, 2))
     scan_raw(u.transpose(1, 2), delta.transpose(1, 2), T(c["A"]), xdbl[:, :, R:R + Nst].transpose(1, 2).unsqueeze(1),
              xdbl[:, :, R + Nst:].transpose(1, 2).unsqueeze(1), T(c["D"]), z, T(c["db"]), True, x=x,
-             z_row_index=perm if c["has_z"] else None, out_row_index=perm, want_out=not c["has_z"], **kw)
+             z_row_index=perm if c["has_z"] else None, out_row_index=perm, want_out=not c["has_z"], **kw, **extra)
     return y, x
 
 
@@ -142,6 +142,32 @@ def test_scan_tok_vs_oracle(dtype, L, has_z, use_perm):
         assert np.allclose(N(y), ref, rtol=3e-2, atol=5e-2)
         assert rel_err(N(y), ref) < 1e-3
     assert rel_err(N(x[:, :, -1, 1::2]), last) < 2e-5
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("use_perm", [True, False])
+def test_scan_tok2_hot_kernel_matches_first_generation_and_preactivated_gate(dtype, use_perm, monkeypatch):
+    """scan_tok2_kernel (LDS-broadcast B/C, packed math) serves the 16-bit / dstate 16 / gate-only calls: bit-identical to
+    scan_tok_kernel (same products and sums in the same order), and with ZIGMA_SCAN_Z_PREACTIVATED it multiplies by z as
+    given (silu applied upstream) — checked against the oracle's ungated y times z."""
+    from zigma_amd import _lib
+    c = _tok_case(3, 64, 192, 16, dtype, True, use_perm, seed=11)
+    info = []
+    y2, _ = _run_tok(c, dtype, info=info)
+    assert info == [_lib.SCAN_KERNEL_TOK2, 0] and _lib.last_kernel() == "scan_tok2_n16"
+    monkeypatch.setenv("ZIGMA_SCAN_KERNEL", "v1")
+    info1 = []
+    y1, _ = _run_tok(c, dtype, info=info1)
+    monkeypatch.delenv("ZIGMA_SCAN_KERNEL")
+    assert info1[0] == _lib.SCAN_KERNEL_TOK and torch.equal(y1, y2)
+    ya, _ = _run_tok(c, dtype, z_preactivated=True)
+    Di = c["u"].shape[2]
+    zt = N(T(c["zfull"][:, :, Di:], dtype))                     # z as the kernel sees it, token order
+    yu, _ = _run_tok(dict(c, has_z=False), dtype)                # ungated y of the first-generation kernel, token order
+    assert rel_err(N(ya), N(yu) * zt) < 3e-3                    # (yu is rounded to 16 bits before this product)
+    if dtype == torch.bfloat16:
+        ref_y, _ = _oracle_tok(dict(c, has_z=False), torch.float32)
+        assert rel_err(N(ya), zo.bf16_round(ref_y * zt)) < 1e-3
 
 
 @pytest.mark.parametrize("slabs_b,Di", [(2, 64), (33, 64 * 64), (65, 64 * 64)])

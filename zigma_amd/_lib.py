@@ -35,8 +35,12 @@ class ScanParams(C.Structure):
             "C_batch_stride", "C_group_stride", "C_d_stride", "C_dstate_stride", "C_l_stride")]
         + [(n, vp) for n in ("u", "delta", "A", "B", "C", "D", "delta_bias", "z", "out", "out_z", "x",
                              "z_row_index", "out_row_index", "checkpoints")]
-        + [("reset_period", i32), ("pad2_", i32)]
+        + [("reset_period", i32), ("pad2_", i32), ("info", C.POINTER(C.c_int32))]
     )
+
+
+SCAN_Z_PREACTIVATED = 2                                   # zigma_scan_params_t.flags
+SCAN_KERNEL_GENERIC, SCAN_KERNEL_TOK, SCAN_KERNEL_TOK2 = 1, 2, 3   # zigma_scan_params_t.info[0]
 
 
 class ConvParams(C.Structure):
@@ -145,7 +149,7 @@ def lib():
         L.zigma_strerror.restype = C.c_char_p
         L.zigma_abi_version.restype = C.c_int
         L.zigma_last_kernel.restype = C.c_char_p
-        if L.zigma_abi_version() != 2:
+        if L.zigma_abi_version() != 3:
             raise RuntimeError("zigma_amd: libzigma_hip.so ABI version mismatch")
         _lib = L
     return _lib

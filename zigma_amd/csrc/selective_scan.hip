@@ -147,6 +147,7 @@ static int launch_generic(const zigma_scan_params_t &p, hipStream_t stream) {
     else ZIGMA_GEN(64, 4)
 #undef ZIGMA_GEN
     set_last_kernel("scan_generic");
+    if (p.info) { p.info[0] = ZIGMA_SCAN_KERNEL_GENERIC; p.info[1] = 0; }
     return check_launch();
 }
 
@@ -181,7 +182,7 @@ extern "C" int zigma_selective_scan_fwd(const zigma_scan_params_t *pp, void *str
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     if (p.batch < 0 || p.dim < 0 || p.seqlen < 0 || p.dstate < 1 || p.dstate > 256) return ZIGMA_ERR_SHAPE;  // MAX_DSTATE
     if (p.n_groups < 1 || p.dim % p.n_groups != 0) return ZIGMA_ERR_SHAPE;
-    if (p.flags != 0) return ZIGMA_ERR_UNSUPPORTED;
+    if (p.flags & ~ZIGMA_SCAN_Z_PREACTIVATED) return ZIGMA_ERR_UNSUPPORTED;
     if (p.batch == 0 || p.dim == 0 || p.seqlen == 0) return ZIGMA_OK;  // empty (pointers may be NULL): nothing to launch
     if (!p.u || !p.delta || !p.A || !p.B || !p.C) return ZIGMA_ERR_NULL;
     if (p.z && !p.out_z) return ZIGMA_ERR_NULL;
@@ -189,6 +190,7 @@ extern "C" int zigma_selective_scan_fwd(const zigma_scan_params_t *pp, void *str
 
     if (p.reset_period < 0 || p.reset_period % 16 != 0 || (p.reset_period > 0 && p.x)) return ZIGMA_ERR_SHAPE;
     if (p.reset_period > 0 && !tok_eligible(p)) return ZIGMA_ERR_STRIDE;   // only the token-major kernel restarts sequences
+    if ((p.flags & ZIGMA_SCAN_Z_PREACTIVATED) && !(tok_eligible(p) && p.io_dtype != ZIGMA_F32)) return ZIGMA_ERR_UNSUPPORTED;
     if (tok_eligible(p)) {
         switch (p.io_dtype) {
             case ZIGMA_BF16: return launch_scan_tok_bf16(p, stream);

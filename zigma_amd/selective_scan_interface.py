@@ -56,10 +56,12 @@ def _as_bgnl(M, name):
 
 def scan_raw(u, delta, A, B, C, D=None, z=None, delta_bias=None, delta_softplus=False, *, out=None, out_z=None,
              x=None, z_row_index=None, out_row_index=None, want_out=True, checkpoints=None, reset_period=0,
-             chunk_len=2048):
+             chunk_len=2048, z_preactivated=False, info=None):
     """Launch zigma_selective_scan_fwd.  All tensors are logical (batch, dim, seqlen) VIEWS with arbitrary
     strides (token-major tensors come in as `.transpose(1, 2)`); B/C are (D, N) f32 or (B, G, N, L) views.
-    Outputs that are None are allocated here with the reference's conventions (out like delta, out_z like z)."""
+    Outputs that are None are allocated here with the reference's conventions (out like delta, out_z like z).
+    z_preactivated: z already holds silu(z) (ZIGMA_SCAN_Z_PREACTIVATED; hot token-major kernel only).
+    info: optional list; receives [kernel family (_lib.SCAN_KERNEL_*), 1 if `checkpoints` is being written]."""
     dev = _lib.require_device(u, delta, A, B, C, D, z, delta_bias, out, out_z, x, z_row_index, out_row_index)
     if u.dim() != 3 or delta.shape != u.shape:
         raise RuntimeError("u and delta must both be (batch, dim, seqlen)")
@@ -80,7 +82,7 @@ def scan_raw(u, delta, A, B, C, D=None, z=None, delta_bias=None, delta_softplus=
     P.batch, P.dim, P.seqlen, P.dstate = batch, dim, L, N
     P.delta_softplus = int(bool(delta_softplus))
     P.io_dtype = _lib.dtype_id(u)
-    P.chunk_len, P.flags = int(chunk_len), 0
+    P.chunk_len, P.flags = int(chunk_len), (_lib.SCAN_Z_PREACTIVATED if z_preactivated else 0)
     P.is_variable_B, P.is_variable_C = int(var_b), int(var_c)
     groups = 1
     bc_dt = None
@@ -154,7 +156,11 @@ def scan_raw(u, delta, A, B, C, D=None, z=None, delta_bias=None, delta_softplus=
             raise RuntimeError("checkpoints must be a contiguous float32 buffer")
         P.checkpoints = _lib.ptr(checkpoints)
     P.reset_period = int(reset_period)       # > 0: independent sequences of that many steps along seqlen
+    status = (_lib.C.c_int32 * 2)(0, 0)
+    P.info = status                          # host out-field: which kernel family ran, whether it writes the checkpoints
     _lib.call("zigma_selective_scan_fwd", P, dev)
+    if info is not None:
+        info[:] = [int(status[0]), int(status[1])]
     return out, out_z
 
 
@@ -310,10 +316,12 @@ class MambaInnerTokFn(torch.autograd.Function):
         ck = None
         if Di % 64 == 0 and N in (8, 16):
             ck = torch.empty(Bsz, Di // 64, (L + 15) // 16, N, 64, device=xz.device, dtype=torch.float32)
+        info = []
         scan_raw(u.transpose(1, 2), delta.transpose(1, 2), A, Bm.transpose(1, 2).unsqueeze(1),
                  Cm.transpose(1, 2).unsqueeze(1), D, z_half.transpose(1, 2), delta_bias, True,
-                 out=out.transpose(1, 2), out_z=y.transpose(1, 2), z_row_index=perm, out_row_index=out_rows, checkpoints=ck)
-        if ck is not None and not _lib.last_kernel().startswith("scan_tok"):
+                 out=out.transpose(1, 2), out_z=y.transpose(1, 2), z_row_index=perm, out_row_index=out_rows, checkpoints=ck,
+                 info=info)
+        if ck is not None and info[1] != 1:          # the kernel that served the call does not write checkpoints
             ck = None
         ctx.save_for_backward(xz, conv_w, conv_b, x_proj_w, dt_proj_w, A, D, delta_bias, u, x_dbl, delta, out)
         ctx.perm, ctx.out_rows, ctx.ck = perm, out_rows, ck
