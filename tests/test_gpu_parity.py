@@ -147,8 +147,8 @@ def test_scan_tok_vs_oracle(dtype, L, has_z, use_perm):
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("use_perm", [True, False])
 def test_scan_tok2_hot_kernel_matches_first_generation_and_preactivated_gate(dtype, use_perm, monkeypatch):
-    """scan_tok2_kernel (LDS-broadcast B/C, packed math) serves the 16-bit / dstate 16 / gate-only calls: bit-identical to
-    scan_tok_kernel (same products and sums in the same order), and with ZIGMA_SCAN_Z_PREACTIVATED it multiplies by z as
+    """scan_tok2_kernel (LDS-broadcast B/C, packed math) serves the 16-bit / dstate 16 / gate-only calls: agrees with
+    scan_tok_kernel to the last-but-one bit, and with ZIGMA_SCAN_Z_PREACTIVATED it multiplies by z as
     given (silu applied upstream) — checked against the oracle's ungated y times z."""
     from zigma_amd import _lib
     c = _tok_case(3, 64, 192, 16, dtype, True, use_perm, seed=11)
@@ -159,7 +159,9 @@ def test_scan_tok2_hot_kernel_matches_first_generation_and_preactivated_gate(dty
     info1 = []
     y1, _ = _run_tok(c, dtype, info=info1)
     monkeypatch.delenv("ZIGMA_SCAN_KERNEL")
-    assert info1[0] == _lib.SCAN_KERNEL_TOK and torch.equal(y1, y2)
+    # same products in the same order; only the sum of the four waves' partials associates differently (fp32), which
+    # moves a few 16-bit results by one ulp
+    assert info1[0] == _lib.SCAN_KERNEL_TOK and rel_err(N(y2), N(y1)) < 5e-4
     ya, _ = _run_tok(c, dtype, z_preactivated=True)
     Di = c["u"].shape[2]
     zt = N(T(c["zfull"][:, :, Di:], dtype))                     # z as the kernel sees it, token order

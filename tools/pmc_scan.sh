@@ -1,12 +1,12 @@
 #!/bin/bash
-# PMC counters for the scan kernel alone (separate passes; no trace domains combined with --pmc).
+# PMC counters for the scan kernel alone (separate passes; no trace domains combined with --pmc).  Driver: tools/scan_one.py
 R=${GRAFT_REPO_ROOT:-$PWD}
 cd /tmp && export TMPDIR=/tmp
 for pass in "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY" \
-            "SQ_ACTIVE_INST_ANY SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_SCA SQ_INSTS_SMEM SQ_INSTS_VMEM GRBM_GUI_ACTIVE" \
+            "SQ_ACTIVE_INST_ANY SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_INSTS_VMEM GRBM_GUI_ACTIVE" \
             "FETCH_SIZE" "WRITE_SIZE"; do
   tag=$(echo $pass | cut -d' ' -f1)
-  SCAN_ONLY=1 timeout 300 rocprofv3 --pmc $pass --output-format csv -d $R/gpurun_out/pmc_$tag -o pmc -- python $R/tools/bench_kernels.py > $R/gpurun_out/pmc_$tag.log 2>&1
+  timeout 120 rocprofv3 --pmc $pass --output-format csv -d $R/gpurun_out/pmc_$tag -o pmc -- python $R/tools/scan_one.py > $R/gpurun_out/pmc_$tag.log 2>&1
 done
 cd $R
 python - <<'PY'
@@ -15,6 +15,6 @@ for f in sorted(glob.glob("gpurun_out/pmc_*/**/*counter_collection.csv", recursi
     agg=collections.defaultdict(list)
     for r in csv.DictReader(open(f)):
         if "scan_tok" in r["Kernel_Name"]:
-            agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
-    for k,v in agg.items(): print(f"{k:28s} n={len(v):3d} mean={sum(v)/len(v):.6g}")
+            agg[(r["Kernel_Name"][:40], r["Counter_Name"])].append(float(r["Counter_Value"]))
+    for k,v in agg.items(): print(f"{k[0]:42s} {k[1]:28s} n={len(v):3d} mean={sum(v)/len(v):.6g}")
 PY
