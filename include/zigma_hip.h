@@ -28,7 +28,7 @@ extern "C" {
 #endif
 
 #define ZIGMA_ABI_VERSION 3   /* 2: parameter blocks grew (row tables in the backward, checkpoints, reset_period)
-                               * 3: scan block: `info` out-field, ZIGMA_SCAN_Z_PREACTIVATED flag */
+                               * 3: scan block: `info` out-field, ZIGMA_SCAN_Z_PREACTIVATED flag; zigma_linear_fwd */
 
 /* zigma_scan_params_t.flags */
 #define ZIGMA_SCAN_Z_PREACTIVATED 2   /* z already holds silu(z) (the in_proj GEMM epilogue applied it): out_z = y * z */
@@ -378,6 +378,30 @@ typedef struct zigma_xproj_params {
 } zigma_xproj_params_t;
 
 int zigma_x_proj_fwd(const zigma_xproj_params_t *p, void *stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Dense projection on the matrix cores:  out = x @ w^T (+ bias) (+ SiLU on a column range), bf16 in / fp32 accumulate / bf16 out.
+ * Replaces the cuBLAS GEMMs behind F.linear at Mamba.in_proj (reference mamba_simple.py:290-294), out_proj
+ * (selective_scan_interface.py:365) and CrossAttention.to_q / to_out (model_zigma.py:104-135).
+ * x: (m, k) rows; w: (n, k) rows (nn.Linear layout); out: (m, n) rows; bias: bf16 (n) or NULL.
+ * silu_from_col: output columns >= this value leave as silu(value) (in_proj writes silu(z) for the gate half, consumed by
+ * the scan under ZIGMA_SCAN_Z_PREACTIVATED); pass n for a plain projection.  Must be a multiple of 32.
+ * Limits: bf16; k % 64 == 0; n % 128 == 0; x / w rows 16-byte aligned, out rows 8-byte aligned.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct zigma_linear_params {
+    int64_t m;
+    int32_t n, k;
+    int32_t dtype;           /* ZIGMA_BF16 */
+    int32_t flags;           /* reserved, must be 0 */
+    int32_t silu_from_col;
+    int32_t pad_;
+    int64_t x_row_stride, w_row_stride, out_row_stride;
+    const void *x, *w;
+    const void *bias;        /* or NULL */
+    void *out;
+} zigma_linear_params_t;
+
+int zigma_linear_fwd(const zigma_linear_params_t *p, void *stream);
 
 /* ------------------------------------------------------------------------------------------ */
 const char *zigma_strerror(int status);

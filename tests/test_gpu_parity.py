@@ -611,3 +611,32 @@ def test_small_batch_sequence_split_matches_single_pass(Bsz, L):
         finally:
             ssi.SPLIT_SMALL_BATCH = True
     assert rel_err(N(y_split), N(y_one)) < 2e-6 and torch.isfinite(y_split).all()
+
+
+@pytest.mark.parametrize("M,K,N,bias,act", [(4096, 640, 2560, False, 1280), (2048, 1280, 640, False, None), (1040, 640, 512, False, None),
+                                           (4096, 512, 640, True, None), (16, 64, 128, True, 64), (272, 128, 384, True, None),
+                                           (65536, 640, 2560, False, 1280)])
+def test_linear_kernel_vs_float64(M, K, N, bias, act):
+    """zigma_linear_fwd (in_proj / out_proj / to_q / to_out on the matrix cores): every output against a float64 evaluation on
+    the same bf16 operands (bias added before the single rounding; SiLU on columns >= act), token counts that are not
+    multiples of the 256-token tile, and a strided (sliced) output."""
+    from zigma_amd import _lib
+    from zigma_amd.linear import linear, linear_eligible
+    g = torch.Generator(device="cpu").manual_seed(M + N)
+    x = torch.randn(M, K, generator=g).to(DEV, torch.bfloat16)
+    w = (torch.randn(N, K, generator=g) * K ** -0.5).to(DEV, torch.bfloat16)
+    b = (torch.randn(N, generator=g) * 0.5).to(DEV, torch.bfloat16) if bias else None
+    assert linear_eligible(x, w, b)
+    y = linear(x, w, b, act)
+    assert _lib.last_kernel().startswith("linear_tn_") and y.shape == (M, N)
+    rows = torch.arange(M, device=DEV) if M <= 4096 else torch.randint(0, M, (2048,), generator=g).to(DEV)
+    ref = x[rows].double() @ w.double().T + (b.double() if bias else 0)
+    if act is not None:
+        ref[:, act:] = torch.nn.functional.silu(ref[:, act:])
+    got = y[rows].double()
+    assert float((got - ref).norm() / ref.norm()) < 2.5e-3              # bf16 rounding of the output: 2^-9 rms
+    assert torch.allclose(got, ref, rtol=1.6e-2, atol=1e-2)
+    if M <= 4096:                                                        # into a column slice of a wider buffer (row pitch != n)
+        wide = torch.zeros(M, N + 128, device=DEV, dtype=torch.bfloat16)
+        linear(x, w, b, act, out=wide[:, 64:64 + N])
+        assert torch.equal(wide[:, 64:64 + N], y) and float(wide[:, :64].abs().max()) == 0 and float(wide[:, 64 + N:].abs().max()) == 0

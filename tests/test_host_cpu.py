@@ -45,7 +45,8 @@ def test_ctypes_structs_match_the_header():
     structs = {"zigma_scan_params_t": _lib.ScanParams, "zigma_conv_params_t": _lib.ConvParams,
                "zigma_norm_params_t": _lib.NormParams, "zigma_dtproj_params_t": _lib.DtProjParams,
                "zigma_scan_bwd_params_t": _lib.ScanBwdParams, "zigma_conv_bwd_params_t": _lib.ConvBwdParams,
-               "zigma_norm_bwd_params_t": _lib.NormBwdParams, "zigma_xattn_params_t": _lib.XAttnParams, "zigma_xproj_params_t": _lib.XProjParams}
+               "zigma_norm_bwd_params_t": _lib.NormBwdParams, "zigma_xattn_params_t": _lib.XAttnParams, "zigma_xproj_params_t": _lib.XProjParams,
+               "zigma_linear_params_t": _lib.LinearParams}
     lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "zigma_hip.h"', "int main(void){"]
     for cname, st in structs.items():
         lines.append(f'printf("{cname} %zu\\n", sizeof({cname}));')

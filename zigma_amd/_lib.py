@@ -114,7 +114,12 @@ class XProjParams(C.Structure):
                 + [(n, i64) for n in ("x_row_stride", "w_row_stride", "out_row_stride")] + [(n, vp) for n in ("x", "w", "out")])
 
 
-EXPORTS = ("zigma_selective_scan_fwd", "zigma_causal_conv1d_fwd", "zigma_add_norm_fwd", "zigma_dt_proj_softplus_fwd", "zigma_cross_attn_fwd", "zigma_x_proj_fwd", "zigma_selective_scan_bwd",
+class LinearParams(C.Structure):
+    _fields_ = ([("m", i64), ("n", i32), ("k", i32), ("dtype", i32), ("flags", i32), ("silu_from_col", i32), ("pad_", i32)]
+                + [(n, i64) for n in ("x_row_stride", "w_row_stride", "out_row_stride")] + [(n, vp) for n in ("x", "w", "bias", "out")])
+
+
+EXPORTS = ("zigma_linear_fwd", "zigma_selective_scan_fwd", "zigma_causal_conv1d_fwd", "zigma_add_norm_fwd", "zigma_dt_proj_softplus_fwd", "zigma_cross_attn_fwd", "zigma_x_proj_fwd", "zigma_selective_scan_bwd",
            "zigma_selective_scan_bwd_workspace_bytes", "zigma_causal_conv1d_bwd",
            "zigma_causal_conv1d_bwd_workspace_bytes", "zigma_add_norm_bwd", "zigma_add_norm_bwd_workspace_bytes",
            "zigma_strerror",
@@ -135,7 +140,8 @@ def lib():
         for name, st in (("zigma_selective_scan_fwd", ScanParams), ("zigma_causal_conv1d_fwd", ConvParams),
                          ("zigma_add_norm_fwd", NormParams), ("zigma_dt_proj_softplus_fwd", DtProjParams),
                          ("zigma_selective_scan_bwd", ScanBwdParams), ("zigma_causal_conv1d_bwd", ConvBwdParams),
-                         ("zigma_add_norm_bwd", NormBwdParams), ("zigma_cross_attn_fwd", XAttnParams), ("zigma_x_proj_fwd", XProjParams)):
+                         ("zigma_add_norm_bwd", NormBwdParams), ("zigma_cross_attn_fwd", XAttnParams), ("zigma_x_proj_fwd", XProjParams),
+                         ("zigma_linear_fwd", LinearParams)):
             fn = getattr(L, name)
             fn.argtypes = [C.POINTER(st), vp]
             fn.restype = C.c_int

@@ -1,0 +1,56 @@
+"""Dense projections on the hand-written MFMA kernel (zigma_linear_fwd): in_proj / out_proj of the Mamba mixer and
+to_q / to_out of the cross-attention (reference call sites mamba_simple.py:290-294, selective_scan_interface.py:365,
+model_zigma.py:104-135, all `F.linear`).  Inference path only: when autograd is recording the callers keep F.linear."""
+import torch
+
+from . import _lib
+
+import os
+
+# Which projections run on zigma_linear_fwd.  Measured at the headline shapes (tools/linear_probe.py, profiles/r02_linear_probe.jsonl;
+# own kernel vs hipBLASLt, us): to_out 54.6 vs 68.0, out_proj 119.6 vs 115.3, to_q 47.5 vs 42.9, in_proj 240.6 vs 190.6.
+#   "auto" (default): the 256 x 128-tile shapes (out features not a multiple of 256, or a bias: out_proj, to_out), where the
+#                     kernel matches or beats the library;   "all": every eligible projection;   "off": library only.
+LINEAR_POLICY = os.environ.get("ZIGMA_LINEAR", "auto")
+
+
+def linear_eligible(x, weight, bias=None):
+    """policy (LINEAR_POLICY) + limits of zigma_linear_fwd: bf16, k % 64 == 0, n % 128 == 0, tokens % 8 == 0, aligned contiguous
+    rows, no autograd"""
+    if not (LINEAR_POLICY != "off" and x.is_cuda and x.dtype == torch.bfloat16 and weight.dtype == torch.bfloat16):
+        return False
+    if LINEAR_POLICY == "auto" and bias is None and weight.shape[0] % 256 == 0:
+        return False
+    if torch.is_grad_enabled() and (x.requires_grad or weight.requires_grad or (bias is not None and bias.requires_grad)):
+        return False
+    n, k = weight.shape
+    if k % 64 or n % 128 or x.shape[-1] != k or x.stride(-1) != 1 or weight.stride(1) != 1:
+        return False
+    if bias is not None and (bias.dtype != torch.bfloat16 or bias.stride(0) != 1):
+        return False
+    m = x.numel() // k
+    if m % 8 or m == 0:
+        return False
+    if x.dim() > 2 and not x.is_contiguous():
+        return False
+    if x.stride(-2) % 8 or weight.stride(0) % 8 or x.data_ptr() % 16 or weight.data_ptr() % 16:
+        return False
+    return m * x.stride(-2) * 2 < 2 ** 31 and n * weight.stride(0) * 2 < 2 ** 31 and 256 * n * 2 < 2 ** 31
+
+
+def linear(x, weight, bias=None, silu_from_col=None, out=None, _probe_flags=0):
+    """out = x @ weight.T (+ bias); output columns >= silu_from_col (a multiple of 32) leave as silu(.)"""
+    dev = _lib.require_device(x, weight, bias, out)
+    lead, k = x.shape[:-1], x.shape[-1]
+    x2 = x.reshape(-1, k)
+    n = weight.shape[0]
+    if out is None:
+        out = torch.empty(x2.shape[0], n, device=x.device, dtype=x.dtype)
+    o2 = out if out.dim() == 2 else out.view(-1, n)            # a view: the kernel writes through the row pitch
+    P = _lib.LinearParams()
+    P.m, P.n, P.k, P.dtype, P.flags = x2.shape[0], n, k, _lib.dtype_id(x), int(_probe_flags)
+    P.silu_from_col = n if silu_from_col is None else int(silu_from_col)
+    P.x_row_stride, P.w_row_stride, P.out_row_stride = x2.stride(0), weight.stride(0), o2.stride(0)
+    P.x, P.w, P.bias, P.out = _lib.ptr(x2), _lib.ptr(weight), _lib.ptr(bias), _lib.ptr(o2)
+    _lib.call("zigma_linear_fwd", P, dev)
+    return out if out.dim() == len(lead) + 1 and out.shape[:-1] == lead else out.view(*lead, n)

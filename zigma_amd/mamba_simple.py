@@ -14,6 +14,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from .linear import linear, linear_eligible
 from .selective_scan_interface import mamba_inner_tok
 
 
@@ -180,7 +181,7 @@ class Mamba(nn.Module):
         if inference_params is not None:
             raise NotImplementedError("zigma_amd: recurrent decoding is out of scope (ZigMa never passes inference_params)")
         batch, seqlen, _ = hidden_states.shape
-        xz = F.linear(hidden_states, self.in_proj.weight, self.in_proj.bias)          # (B, L, 2*Di) token-major
+        xz = self._proj(hidden_states, self.in_proj)                                  # (B, L, 2*Di) token-major
         A, Dp, dtb = self._scan_consts("")
         fwd = lambda t, perm: mamba_inner_tok(t, self.conv1d.weight, self.conv1d.bias, self.x_proj.weight,
                                                self.dt_proj.weight, A, Dp, dtb,
@@ -224,4 +225,11 @@ class Mamba(nn.Module):
                 raise NotImplementedError
         else:
             raise NotImplementedError
-        return F.linear(y, self.out_proj.weight, self.out_proj.bias)
+        return self._proj(y, self.out_proj)
+
+    @staticmethod
+    def _proj(x, lin):
+        """in_proj / out_proj: the hand-written MFMA kernel where it applies (zigma_amd.linear), the library otherwise"""
+        if linear_eligible(x, lin.weight, lin.bias):
+            return linear(x, lin.weight, lin.bias)
+        return F.linear(x, lin.weight, lin.bias)

@@ -30,6 +30,7 @@ from torch import Tensor
 
 from .attention import cross_attn, cross_attn_eligible
 from .layernorm import RMSNorm, block_norm, layer_norm_fn, rms_norm_fn
+from .linear import linear, linear_eligible
 from .mamba_simple import Mamba
 from .scan_paths import hilbert_path, reverse_permut_np, zigzag_path
 
@@ -106,15 +107,22 @@ class CrossAttention(nn.Module):
         self.to_v = nn.Linear(context_dim, inner_dim, bias=False)
         self.to_out = nn.Sequential(nn.Linear(inner_dim, query_dim), nn.Dropout(dropout))
 
+    @staticmethod
+    def _proj(x, lin):
+        if linear_eligible(x, lin.weight, lin.bias):
+            return linear(x, lin.weight, lin.bias)
+        return F.linear(x, lin.weight, lin.bias)
+
     def forward(self, x, text, mask=None, kv=None):
         """kv: optional precomputed (to_k(text), to_v(text)), each (B, n_ctx, inner) — ZigMa.forward batches these
         projections of all layers into one GEMM since `text` is the same for every block."""
         Bsz, L, _ = x.shape
         H = self.heads
-        q = self.to_q(x)
+        q = self._proj(x, self.to_q)
         k, v = kv if kv is not None else (self.to_k(text), self.to_v(text))
         if not torch.is_grad_enabled() and cross_attn_eligible(q, k, v, H):
-            return self.to_out(cross_attn(q, k, v, H, self.scale))      # HIP kernel: one pass, K/V of the head in LDS
+            # HIP kernels: attention core in one pass (K/V of the head in LDS), to_out on the MFMA projection kernel
+            return self.to_out[1](self._proj(cross_attn(q, k, v, H, self.scale), self.to_out[0]))
         q = q.view(Bsz, L, H, -1).transpose(1, 2)
         k = k.reshape(Bsz, k.shape[1], H, -1).transpose(1, 2)
         v = v.reshape(Bsz, v.shape[1], H, -1).transpose(1, 2)
