@@ -291,6 +291,25 @@ def test_oracle_model_vs_r2_reference_goldens():
     assert rel_err(out, g["out"]) < 2e-5, rel_err(out, g["out"])
 
 
+def test_postprocess_matches_reference_formulas():
+    """sample_acc.py:319-321,362-377: latent / 0.18215 -> decode -> clamp(127.5 x + 128, 0, 255) -> uint8 (truncation);
+    video latents decoded per sample and stacked along dim 1."""
+    from zigma_amd import postprocess as pp
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(3, 4, 8, 8, generator=g)
+    dec = lambda z: torch.tanh(z[:, :3].repeat_interleave(2, -1).repeat_interleave(2, -2))      # toy "VAE": 4x8x8 -> 3x16x16
+    got = pp.finish_samples(x, dec, world=1)
+    ref = torch.clamp(127.5 * dec(x / 0.18215) + 128.0, 0, 255).to(dtype=torch.uint8)
+    assert got.dtype == torch.uint8 and got.shape == (3, 3, 16, 16) and torch.equal(got, ref)
+    assert torch.equal(pp.to_uint8(torch.tensor([-1.5, -1.0, 0.0, 0.999, 1.0, 2.0])),
+                       torch.tensor([0, 0, 128, 255, 255, 255], dtype=torch.uint8))
+    assert torch.equal(pp.finish_samples(x, None, world=1), pp.to_uint8(x))                       # pixel-space model: no decode
+    v = torch.randn(2, 5, 4, 8, 8, generator=g)
+    gv = pp.decode_latents(v, dec, is_video=True)
+    rv = torch.stack([dec(v[i] / 0.18215) for i in range(2)], dim=1)
+    assert gv.shape == (5, 2, 3, 16, 16) and torch.equal(gv, rv)
+
+
 def test_drop_path_is_applied_once_per_block_in_train_mode(monkeypatch):
     """Stochastic depth (reference model_zigma.py:406-437,963-975): once per block on the incoming branch when a residual
     stream exists, once before the final norm.  DropPath is mocked to the deterministic x -> 2x so a double application

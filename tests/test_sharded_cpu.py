@@ -33,7 +33,12 @@ def _worker(rank, world, port, q):
     calls = []
     import time
     el = ss.timed_steps(lambda: (calls.append(1), time.sleep(0.02 * (rank + 1))), steps=3, warmup=2, device="cpu", world=world)
-    q.put((rank, ok_gather, len(calls), el, tuple(out.shape)))
+    # 3) the step after the ODE (sample_acc.py:363-392,435): decode -> uint8 -> gather in rank order
+    from zigma_amd import postprocess as pp
+    img = pp.finish_samples(torch.full((2, 3, 4, 4), float(rank)), decode=lambda z: z * pp.LATENT_SCALE - 0.5)
+    ok_img = img.dtype == torch.uint8 and img.shape == (4, 3, 4, 4) and \
+        torch.equal(img[:2], pp.to_uint8(torch.full((2, 3, 4, 4), -0.5))) and torch.equal(img[2:], pp.to_uint8(torch.full((2, 3, 4, 4), 0.5)))
+    q.put((rank, ok_gather and ok_img, len(calls), el, tuple(out.shape)))
     dist.destroy_process_group()
 
 
@@ -62,3 +67,14 @@ def test_local_batch_and_seed_rules():
     assert ss.local_batch(64, 3, 8) == 8 and ss.rank_seed(7, 3) == 10
     with pytest.raises(ValueError):
         ss.local_batch(10, 0, 4)
+
+
+def test_bench_refuses_a_multi_gpu_run_it_cannot_launch():
+    """`python bench.py --gpus N` spawns N ranks itself (torch.distributed.run); with fewer visible GPUs it must fail loudly
+    instead of reporting a smaller job (VERDICT r1, weak #7)."""
+    sys.path.insert(0, ROOT)
+    import bench
+    have = torch.cuda.device_count()
+    with pytest.raises(SystemExit) as e:
+        bench.respawn_under_launcher(have + 2)
+    assert "refusing" in str(e.value)
