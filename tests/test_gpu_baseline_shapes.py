@@ -167,7 +167,7 @@ def test_config4_l16384_conv_scan_carries():
     from zigma_amd.scan_paths import zigzag_path
     from zigma_amd.selective_scan_interface import dt_proj_softplus, mamba_inner_tok, scan_raw, split_chunk_len, x_proj
     Bsz, L, Di, R, Nst = 4, 16384, 1280, 40, 16
-    assert split_chunk_len(Bsz, Di, L) == 2048
+    assert split_chunk_len(Bsz, Di, L) == 1024          # what mamba_inner_tok picks: 80 workgroups x 16 chunks = 5 per CU
     w = _inner_weights(Di, R, Nst, seed=4)
     g = torch.Generator().manual_seed(9)
     xz = torch.randn(Bsz, L, 2 * Di, generator=g).bfloat16()
@@ -188,7 +188,9 @@ def test_config4_l16384_conv_scan_carries():
                  out_z=y.transpose(1, 2), z_row_index=p32, out_row_index=p32, want_out=False, x=xc, chunk_len=2048)
         assert _lib.last_kernel().startswith("scan_tok")
         y_inner = mamba_inner_tok(xzd, cw, cb, xw, dw, A, D, db, perm=p32, out_rows=p32)
-    assert torch.equal(y_inner, y)                                # the op the model calls == the stages above
+    # the op the model calls == the stages above (it splits into 1024-step chunks: the carries are combined in another
+    # association, fp32 rounding only)
+    assert rel_err(N(y_inner), N(y)) < 1e-4
     for b, slab in ((0, 3), (3, 16)):
         sl = slice(slab * 64, slab * 64 + 64)
         xz_b = xz[b].float().numpy()

@@ -379,7 +379,8 @@ def test_sequence_split_policy():
     assert split_chunk_len(64, 1280, 1024) == 0                      # headline batch: 1280 workgroups, single pass
     assert split_chunk_len(1, 1280, 1024) == 32                      # one sample: 20 workgroups -> 32 chunks of 32 steps
     assert split_chunk_len(4, 1280, 1024) == 112 and split_chunk_len(16, 1280, 1024) == 0
-    assert split_chunk_len(4, 1280, 16384) == 2048 and split_chunk_len(64, 1280, 16384) == 0
+    assert split_chunk_len(4, 1280, 16384) == 1024 and split_chunk_len(64, 1280, 16384) == 0   # 80 wgs x 16 chunks = 5 per CU
+    assert split_chunk_len(1, 1280, 16384) == 256 and split_chunk_len(30, 1280, 4096) == 1376
     assert split_chunk_len(1, 1280, 128) == 0 and split_chunk_len(2, 1536, 4096, reset_period=16) == 0
     for b in range(1, 11):
         c = split_chunk_len(b, 1280, 1024)

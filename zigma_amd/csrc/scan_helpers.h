@@ -37,6 +37,19 @@ __device__ __forceinline__ void step_h(float dv, float du, float Bf, const float
         : "v"(dv), "v"(du), "v"(a2[0]), "v"(a2[1]), "v"(a2[2]), "v"(a2[3]), "v"(Bf),
           "i"(S * 4 + 0), "i"(S * 4 + 1), "i"(S * 4 + 2), "i"(S * 4 + 3));
 }
+// The same step with B as plain (LDS-broadcast) operands — state-only pass of scan_tok2_kernel.
+__device__ __forceinline__ void step_h_plain(float dv, float du, float b0, float b1, float b2, float b3, const float (&a2)[4],
+                                             float (&h)[4]) {
+    float t0, t1, t2, t3, p0, p1, p2, p3;
+    asm volatile(
+        "v_mul_f32 %4, %12, %14\n\tv_mul_f32 %5, %12, %15\n\tv_mul_f32 %6, %12, %16\n\tv_mul_f32 %7, %12, %17\n\t"
+        "v_exp_f32 %4, %4\n\tv_exp_f32 %5, %5\n\tv_exp_f32 %6, %6\n\tv_exp_f32 %7, %7\n\t"
+        "v_mul_f32 %8, %18, %13\n\tv_mul_f32 %9, %19, %13\n\tv_mul_f32 %10, %20, %13\n\tv_mul_f32 %11, %21, %13\n\t"
+        "v_fma_f32 %0, %4, %0, %8\n\tv_fma_f32 %1, %5, %1, %9\n\tv_fma_f32 %2, %6, %2, %10\n\tv_fma_f32 %3, %7, %3, %11"
+        : "+v"(h[0]), "+v"(h[1]), "+v"(h[2]), "+v"(h[3]), "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3),
+          "=&v"(p0), "=&v"(p1), "=&v"(p2), "=&v"(p3)
+        : "v"(dv), "v"(du), "v"(a2[0]), "v"(a2[1]), "v"(a2[2]), "v"(a2[3]), "v"(b0), "v"(b1), "v"(b2), "v"(b3));
+}
 __device__ __forceinline__ void dpp_settle(float &c) { asm volatile("s_nop 1" : "+v"(c)); }
 
 using rsrc_t = __amdgpu_buffer_rsrc_t;

@@ -32,12 +32,15 @@ def split_chunk_len(batch, d_inner, seqlen, reset_period=0):
     """Chunk length (a multiple of 16) for the sequence-split mode of the token-major scan, or 0 for a single pass.
     The plain grid is batch * d_inner / 64 workgroups; the split pays (it runs the recurrence twice) only when that
     leaves most of the 256 CUs idle: small batches at L >= 256 (threshold from tools/split_threshold_probe.py), or
-    long sequences (L >= 4096, the reference's own 2048-step chunks)."""
+    long sequences (L >= 4096: chunks of at most the reference's 2048 steps, sized for ~5 workgroups per CU)."""
     wgs = batch * (d_inner // 64)
     if reset_period or wgs < 1:
         return 0
-    if seqlen >= 4096:
-        return 2048 if wgs < 768 else 0
+    if seqlen >= 4096:                                            # long sequences: ~1280 workgroups = 5 per CU, all resident
+        if wgs >= 768:
+            return 0
+        per = -(-seqlen // -(-1280 // wgs))
+        return min(2048, max(256, (per + 15) // 16 * 16))
     if not (SPLIT_SMALL_BATCH and wgs <= SPLIT_MAX_WGS and seqlen >= 256):
         return 0
     per = -(-seqlen // -(-768 // wgs))                            # steps per chunk that give ~768 workgroups
