@@ -7,10 +7,13 @@ from . import _lib
 
 import os
 
-# Which projections run on zigma_linear_fwd.  Measured at the headline shapes (tools/linear_probe.py, profiles/r02_linear_probe.jsonl;
-# own kernel vs hipBLASLt, us): to_out 54.6 vs 68.0, out_proj 119.6 vs 115.3, to_q 47.5 vs 42.9, in_proj 240.6 vs 190.6.
-#   "auto" (default): the 256 x 128-tile shapes (out features not a multiple of 256, or a bias: out_proj, to_out), where the
-#                     kernel matches or beats the library;   "all": every eligible projection;   "off": library only.
+# Which projections run on zigma_linear_fwd.  Measured at the headline shapes, own kernel vs hipBLASLt in us (stand-alone:
+# tools/linear_probe.py, profiles/r02_linear_probe.jsonl; inside the forward: profiles/r02_b_bench_kernel_stats.csv):
+#   to_out (bias) 54.6 vs 68.0 stand-alone, 61 vs 71 in the forward;  out_proj 119.6 vs 115.3 stand-alone but 153 vs 127 in the
+#   forward (its operand was just written by the scan: the one-step-deep prefetch shows the HBM latency);  to_q 47.5 vs 42.9;
+#   in_proj 240.6 vs 190.6.
+#   "auto" (default): projections with a bias (to_out), where the kernel beats the library;  "all": every eligible projection;
+#   "off": library only.
 LINEAR_POLICY = os.environ.get("ZIGMA_LINEAR", "auto")
 
 
@@ -19,7 +22,7 @@ def linear_eligible(x, weight, bias=None):
     rows, no autograd"""
     if not (LINEAR_POLICY != "off" and x.is_cuda and x.dtype == torch.bfloat16 and weight.dtype == torch.bfloat16):
         return False
-    if LINEAR_POLICY == "auto" and bias is None and weight.shape[0] % 256 == 0:
+    if LINEAR_POLICY == "auto" and bias is None:
         return False
     if torch.is_grad_enabled() and (x.requires_grad or weight.requires_grad or (bias is not None and bias.requires_grad)):
         return False
