@@ -198,6 +198,21 @@ __global__ __launch_bounds__(512, 2) void linear_tn_kernel(const zigma_linear_pa
                     for (int mb = 0; mb < MB; ++mb)
                         acc[nb][mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ks & 1][nb], b[ks & 1][mb], acc[nb][mb], 0, 0, 0);
             }
+            // Pin the order hipcc would otherwise collapse to [all reads of a sub-step -> wait -> its MFMAs]: the NB + MB reads of
+            // sub-step ks + 1 are issued one by one between the first MFMAs of sub-step ks (masks: 0x100 DS read, 0x008 MFMA).
+            {
+                __builtin_amdgcn_sched_group_barrier(0x100, NB + MB, 0);
+#pragma unroll
+                for (int ks = 0; ks + 1 < kLinBK / 16; ++ks) {
+#pragma unroll
+                    for (int r = 0; r < NB + MB; ++r) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                    }
+                    __builtin_amdgcn_sched_group_barrier(0x008, NB * MB - (NB + MB), 0);
+                }
+                __builtin_amdgcn_sched_group_barrier(0x008, NB * MB, 0);
+            }
             buf ^= 1;
         }
         // ---- epilogue: transposed through the stage the main loop has just finished with ----------------------------------------
@@ -220,6 +235,127 @@ __global__ __launch_bounds__(512, 2) void linear_tn_kernel(const zigma_linear_pa
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// Third arrangement: TWO workgroups per CU.  128 tokens x 256 features per workgroup, 4 waves (one per SIMD, wave tile 64 x 128 as
+// in the 256 x 256 kernel), BK = 32, two 24 KB stages -> 48 KB of LDS and <= 256 VGPRs per wave, so two workgroups share a CU.
+// The first pipeline's loss is structural: one workgroup per CU means every wave of the CU waits at the same barrier, loads
+// are exposed whenever they take longer than one k-step, and nothing runs during the epilogue's stores.  Two independent
+// workgroups per CU interleave on their own (the CU's other workgroup issues MFMAs while this one waits or stores), at the
+// price of 1.5 x the L2 -> LDS traffic per flop (128 x 256 instead of 256 x 256 tiles).
+template <bool HAS_BIAS>
+__global__ __launch_bounds__(256, 2) void linear_tn3_kernel(const zigma_linear_params_t p, const int tiles_m, const int tiles_n) {
+    constexpr int BM = 128, BN = 256, BK = 32, MB = 4, NB = 2;
+    constexpr int ROWS = BN + BM, STAGE = ROWS * BK * 2;         // 24 KB per stage: W rows first, then token rows (64 B each)
+    constexpr int NLD = STAGE / 1024 / 4;                          // 6 direct-to-LDS loads per wave per stage (16 rows x 64 B each)
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[2 * STAGE + (HAS_BIAS ? 32768 : 0)];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // = n position of the wave tile (4 x 64 features)
+    const int j = lane & 31, kh = lane >> 5;
+    const int nk = p.k / BK;
+    const unsigned char *xb = reinterpret_cast<const unsigned char *>(p.x);
+    const unsigned char *wb = reinterpret_cast<const unsigned char *>(p.w);
+    const int64_t x_pitch = p.x_row_stride * 2, w_pitch = p.w_row_stride * 2;
+
+    const int n_tiles = tiles_m * tiles_n;
+    const int xcd = blockIdx.x & 7, slot_in_xcd = blockIdx.x >> 3, wg_per_xcd = gridDim.x >> 3;
+    const int chunk = (n_tiles + 7) >> 3;
+    const int chunk_end = (xcd + 1) * chunk < n_tiles ? (xcd + 1) * chunk : n_tiles;
+    int tile = xcd * chunk + slot_in_xcd;
+    if (tile >= chunk_end) return;
+
+    // staging: instruction i of wave w fills rows q*16 .. q*16+15 of a stage, q = i * 4 + w (W rows first: i < 4);
+    // lane -> row (lane >> 2), 16-byte slot (lane & 3) holding source piece (lane & 3) ^ ((row >> 2) & 3)
+    const int srow = wave * 16 + (lane >> 2);
+    const unsigned piece = ((lane & 3) ^ ((lane >> 4) & 3)) << 4;
+    const unsigned lane_off_w = static_cast<unsigned>(srow * w_pitch) + piece, lane_off_x = static_cast<unsigned>(srow * x_pitch) + piece;
+    auto stage = [&](int buf, int t, int kt) {
+        const int mt = t / tiles_n, nt = t - mt * tiles_n;
+        const unsigned char *wbase = wb + static_cast<int64_t>(nt) * BN * w_pitch + kt * (BK * 2);
+        const unsigned char *xbase = xb + static_cast<int64_t>(mt) * BM * x_pitch + kt * (BK * 2);
+        const int64_t rows_left = p.m - static_cast<int64_t>(mt) * BM;      // m % 16 == 0: a group of 16 rows exists or does not
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) {
+            const unsigned char *src;
+            if (i < BN / 64) {
+                src = wbase + static_cast<int64_t>(i * 64) * w_pitch + lane_off_w;
+            } else {
+                const int r0 = (i - BN / 64) * 64;
+                src = xbase + (r0 + wave * 16 < rows_left ? static_cast<int64_t>(r0) * x_pitch : -static_cast<int64_t>(wave * 16) * x_pitch) + lane_off_x;
+            }
+            __builtin_amdgcn_global_load_lds((gbl_ptr_t)(src), (lds_ptr_t)(smem) + buf * STAGE + (i * 4 + wave) * 1024, 16, 0, 0);
+        }
+    };
+    // fragment reads: row * 64 + ((ksub * 2 + kh) ^ ((row >> 2) & 3)) * 16, row = base (multiple of 32) + j
+    const int sw = (j >> 2) & 3;
+    const int a_row0 = (wave * 64 + j) * 64, b_row0 = (BN + j) * 64;
+    const int off0 = ((kh ^ sw) << 4), off1 = (((2 | kh) ^ sw) << 4);
+
+    if (HAS_BIAS) {
+        for (int i = tid; i < p.n / 2; i += 256)
+            reinterpret_cast<uint32_t *>(smem + 2 * STAGE)[i] = reinterpret_cast<const uint32_t *>(p.bias)[i];
+    }
+    int buf = 0;
+    stage(0, tile, 0);
+#pragma unroll 1
+    while (true) {
+        const int next = tile + wg_per_xcd;
+        const bool has_next = next < chunk_end;
+        f32x16 acc[NB][MB];
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+            for (int mb = 0; mb < MB; ++mb) acc[nb][mb] = f32x16{};
+#pragma unroll 1
+        for (int kt = 0; kt < nk; ++kt) {
+            __syncthreads();
+            if (kt + 1 < nk) stage(buf ^ 1, tile, kt + 1);
+            else if (has_next) stage(buf ^ 1, next, 0);
+            const unsigned char *sb = smem + buf * STAGE;
+            bf16x8 a[2][NB], b[2][MB];
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                const int off = ks ? off1 : off0;
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb)
+                    a[ks][nb] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4 *>(sb + a_row0 + nb * 32 * 64 + off));
+#pragma unroll
+                for (int mb = 0; mb < MB; ++mb)
+                    b[ks][mb] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4 *>(sb + b_row0 + mb * 32 * 64 + off));
+            }
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+                    for (int mb = 0; mb < MB; ++mb)
+                        acc[nb][mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ks][nb], b[ks][mb], acc[nb][mb], 0, 0, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, NB + MB, 0);       // reads of sub-step 1 between the MFMAs of sub-step 0
+#pragma unroll
+            for (int r = 0; r < NB + MB; ++r) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            }
+            __builtin_amdgcn_sched_group_barrier(0x008, 2 * NB * MB - (NB + MB), 0);
+            buf ^= 1;
+        }
+        if (!(p.flags & 0x400)) {
+            __syncthreads();                                                                  // every wave is done with the fragments of this stage
+            const int mt = tile / tiles_n, nt = tile - mt * tiles_n;
+            const int64_t m_tile = static_cast<int64_t>(mt) * BM;
+            const int64_t rows_here = p.m - m_tile;
+            const int64_t o_pitch = p.out_row_stride * 2;
+            const rsrc_t o_rs = make_rsrc(reinterpret_cast<unsigned char *>(p.out) + m_tile * o_pitch + (nt * BN + wave * 64) * 2,
+                                          rows_here > 0 ? (rows_here < BM ? rows_here : BM) * o_pitch - (nt * BN + wave * 64) * 2 : 0);
+            linear_epilogue<MB, NB>(acc, smem + (buf ^ 1) * STAGE + wave * 4096,
+                                    HAS_BIAS ? reinterpret_cast<const uint16_t *>(smem + 2 * STAGE) : nullptr, o_rs, o_pitch, nt * BN + wave * 64,
+                                    p.silu_from_col, lane);
+        }
+        if (!has_next) break;
+        tile = next;
+    }
+}
 
 // ---------------------------------------------------------------------------------------------------------------------------
 // Second pipeline: the same tiles, fragments and epilogue, but the k-loop runs in HALF steps of 32 columns through a ring of
@@ -358,7 +494,7 @@ extern "C" int zigma_linear_fwd(const zigma_linear_params_t *pp, void *stream_) 
     (void)hipGetLastError();
     const zigma_linear_params_t &p = *pp;
     if (p.m < 0 || p.n < 1 || p.k < 1) return ZIGMA_ERR_SHAPE;
-    if (p.flags & ~0x1f00) return ZIGMA_ERR_UNSUPPORTED;     // 0x100 ... 0x1000: timing / A-B probes (tools/linear_probe.py)
+    if (p.flags & ~0x7f00) return ZIGMA_ERR_UNSUPPORTED;     // 0x100 ... 0x1000: timing / A-B probes (tools/linear_probe.py)
     if (p.m == 0) return ZIGMA_OK;
     if (!p.x || !p.w || !p.out) return ZIGMA_ERR_NULL;
     if (p.dtype != ZIGMA_BF16) return ZIGMA_ERR_DTYPE;
@@ -381,6 +517,17 @@ extern "C" int zigma_linear_fwd(const zigma_linear_params_t *pp, void *stream_) 
     if (n_tiles > 0x7fffffff) return ZIGMA_ERR_SHAPE;
     int grid = 256;                                  // one persistent workgroup per CU; multiples of 8 keep the XCD map
     if (n_tiles < grid) grid = static_cast<int>((n_tiles + 7) / 8 * 8);
+    if ((p.flags & 0x2000) && p.n % 256 == 0 && p.m % 16 == 0) {        // 0x2000: two workgroups per CU, 128 x 256 tiles
+        const int tm = static_cast<int>((p.m + 127) / 128), tn = p.n / 256;
+        const int64_t nt3 = static_cast<int64_t>(tm) * tn;
+        if (nt3 > 0x7fffffff) return ZIGMA_ERR_SHAPE;
+        int g3 = 512;
+        if (nt3 < g3) g3 = static_cast<int>((nt3 + 7) / 8 * 8);
+        if (p.bias) hipLaunchKernelGGL((linear_tn3_kernel<true>), dim3(g3), dim3(256), 0, stream, p, tm, tn);
+        else hipLaunchKernelGGL((linear_tn3_kernel<false>), dim3(g3), dim3(256), 0, stream, p, tm, tn);
+        set_last_kernel("linear_tn3_128x256");
+        return check_launch();
+    }
     if (ring) {
         if (wide) hipLaunchKernelGGL((linear_tn2_kernel<4, false>), dim3(grid), dim3(512), 0, stream, p, tiles_m, tiles_n);
         else if (p.bias) hipLaunchKernelGGL((linear_tn2_kernel<2, true>), dim3(grid), dim3(512), 0, stream, p, tiles_m, tiles_n);
