@@ -113,6 +113,17 @@ __global__ __launch_bounds__(256) void conv_generic_kernel(const zigma_conv_para
 template <typename IO, typename WT>
 static int launch_conv(const zigma_conv_params_t &p, hipStream_t stream) {
     constexpr size_t es = sizeof(typename IO::raw);
+    if (p.batch > 65535) {              // batch rides in gridDim.z: larger batches (video: batch x tokens-per-frame rows) go in slices
+        for (int b0 = 0; b0 < p.batch; b0 += 65535) {
+            zigma_conv_params_t q = p;
+            q.batch = p.batch - b0 < 65535 ? p.batch - b0 : 65535;
+            q.x = reinterpret_cast<const char *>(p.x) + static_cast<int64_t>(b0) * p.x_batch_stride * es;
+            q.out = reinterpret_cast<char *>(p.out) + static_cast<int64_t>(b0) * p.out_batch_stride * es;
+            const int rc = launch_conv<IO, WT>(q, stream);
+            if (rc != ZIGMA_OK) return rc;
+        }
+        return ZIGMA_OK;
+    }
     const bool tok = p.x_c_stride == 1 && p.out_c_stride == 1 && p.dim % 4 == 0 &&
                      reinterpret_cast<uintptr_t>(p.x) % (4 * es) == 0 && reinterpret_cast<uintptr_t>(p.out) % (4 * es) == 0 &&
                      p.x_l_stride % 4 == 0 && p.out_l_stride % 4 == 0 && p.x_batch_stride % 4 == 0 && p.out_batch_stride % 4 == 0 &&

@@ -72,7 +72,7 @@ __global__ __launch_bounds__(64 * kDtWaves) void dt_proj_softplus_kernel(const z
         for (int r = 0; r < 16; ++r) {
             const int dm = (r & 3) + 8 * (r >> 2);
             float ve = ce[r] + b_e, vo = co[r] + b_o;
-            if (p.softplus) { ve = softplus20(ve); vo = softplus20(vo); }
+            if (p.softplus) { ve = softplus20_r16(ve); vo = softplus20_r16(vo); }
             const uint32_t pk = static_cast<uint32_t>(from_float<BF16>(ve)) | (static_cast<uint32_t>(from_float<BF16>(vo)) << 16);
             if (full || m0 + 4 * kh + dm < p.m) *reinterpret_cast<uint32_t *>(orow + dm * p.out_row_stride) = pk;
         }
