@@ -642,3 +642,26 @@ def test_linear_kernel_vs_float64(M, K, N, bias, act, monkeypatch):
         wide = torch.zeros(M, N + 128, device=DEV, dtype=torch.bfloat16)
         linear(x, w, b, act, out=wide[:, 64:64 + N])
         assert torch.equal(wide[:, 64:64 + N], y) and float(wide[:, :64].abs().max()) == 0 and float(wide[:, 64 + N:].abs().max()) == 0
+
+
+def test_batch_beyond_the_grid_limit_runs_in_slices():
+    """batch > 65535 (the differentiable video temporal path reshapes to (batch * K, T, C)): conv and scan forward slice the
+    batch instead of failing the launch; compared with the same rows run as a small batch."""
+    from zigma_amd.causal_conv1d_interface import causal_conv1d_raw
+    from zigma_amd.selective_scan_interface import scan_raw
+    Bsz, L, Di, Nst = 65536 + 40, 16, 64, 16
+    g = torch.Generator(device="cpu").manual_seed(3)
+    mk = lambda *s_: torch.randn(*s_, generator=g).to(DEV)
+    x, w, bias = mk(Bsz, L, Di), mk(Di, 4), mk(Di)
+    u = torch.empty(Bsz, L, Di, device=DEV)
+    causal_conv1d_raw(x.transpose(1, 2), w, bias, True, out=u.transpose(1, 2))
+    sel = torch.tensor([0, 1, 65534, 65535, 65536, Bsz - 1], device=DEV)
+    u_ref = torch.empty(len(sel), L, Di, device=DEV)
+    causal_conv1d_raw(x[sel].transpose(1, 2), w, bias, True, out=u_ref.transpose(1, 2))
+    assert torch.equal(u[sel], u_ref)
+    delta, xd, z = 0.5 * torch.rand(Bsz, L, Di, generator=g).to(DEV), mk(Bsz, L, 2 * Nst), mk(Bsz, L, Di)
+    A, D = -torch.rand(Di, Nst, generator=g).to(DEV), mk(Di)
+    run = lambda s_: scan_raw(u[s_].transpose(1, 2), delta[s_].transpose(1, 2), A, xd[s_][:, :, :Nst].transpose(1, 2).unsqueeze(1),
+                              xd[s_][:, :, Nst:].transpose(1, 2).unsqueeze(1), D, z[s_].transpose(1, 2), None, False, want_out=False)[1]
+    y = run(slice(None))
+    assert torch.equal(y[sel], run(sel))

@@ -1,0 +1,548 @@
+// Dense projections of the ZigMa block on the CDNA4 matrix cores: out = x @ W^T (+ bias) (+ SiLU on a column range), bf16.
+// C ABI: zigma_linear_fwd.
+//
+// Replaces the cuBLAS GEMMs behind F.linear at the reference's call sites Mamba.in_proj (mamba_simple.py:290-294),
+// out_proj (selective_scan_interface.py:365) and CrossAttention.to_q / to_out (model_zigma.py:104-135).  Shapes at the
+// headline config (M = B*L = 65 536 tokens): in_proj 640 -> 2560, out_proj 1280 -> 640, to_q 640 -> 512, to_out 512 -> 640:
+// K is SHORT (8 - 20 k-steps of 64) and the output is as large as the input, so a tile's prologue / epilogue and the C
+// write-back matter as much as the main loop.  Design (MI355X: 256 CUs, 160 KB LDS, v_mfma_f32_32x32x16_bf16):
+//
+//   * "TN": both operands are K-contiguous (activations token-major, nn.Linear weights (N, K)): every MFMA fragment is one
+//     16-byte piece of a row.  The product is evaluated TRANSPOSED, D[n][m] = sum_k W[n][k] x[m][k] (W rows as the MFMA
+//     A operand, tokens as the B operand): a lane then holds 4 CONSECUTIVE output features of ONE token per accumulator
+//     quad, so results leave as packed 8-byte pieces of an output row (row-major out, no transpose pass).
+//   * workgroup tile 256 tokens x BN features (BN = 256: 8 waves as 4 (N) x 2 (M), wave tile 64 x 128; BN = 128: 2 x 4, wave
+//     tile 64 x 64), BK = 64, one workgroup per CU, persistent: a workgroup walks its list of tiles and the k-steps of all
+//     of them as ONE software pipeline — the first k-step of the next tile is already in flight while the epilogue of
+//     the current tile stores.
+//   * operands reach LDS by direct-to-LDS loads (global_load_lds_dwordx4, 1 KB per wave instruction, no VGPR round trip,
+//     no ds_write), two stages of (BN + 256) rows x 128 B; ONE barrier per k-step.  The LDS image is lane-linear, so the
+//     bank swizzle (16-byte slot ^= (row >> 1) & 7: conflict-free ds_read_b128 for 32 consecutive rows) is applied to the
+//     per-lane SOURCE address and again on the fragment reads (cdna_hip_programming.md T2 / rule 21).
+//   * tile order is XCD-aware: the 32 workgroups of an XCD (blockIdx % 8) work at any time on ~32 consecutive tiles of the
+//     (m-tile, n-tile) raster, i.e. a few 256-token activation panels x all weight panels: both stay in that XCD's 4 MB L2.
+//   * epilogue in registers: + bias, SiLU on output columns >= silu_from_col (in_proj emits silu(z) for the gate half:
+//     the scan then multiplies instead of evaluating exp + rcp per element, ZIGMA_SCAN_Z_PREACTIVATED), bf16 pack.
+#include "scan_helpers.h"
+
+namespace zigma {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __attribute__((address_space(3))) unsigned char *lds_ptr_t;
+typedef const __attribute__((address_space(1))) void *gbl_ptr_t;
+
+constexpr int kLinBM = 256, kLinBK = 64;
+
+// Epilogue of one wave tile (64 features x MB * 32 tokens), shared by both pipelines.
+// D[i][jj]: jj = token (lane & 31), i = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5) = output feature: a lane holds 8-byte pieces of
+// 32 different output rows, and storing them as they lie costs one memory request per row per instruction (measured: the
+// scattered form made the stores the longest phase of the kernel).  So the wave transposes its tile through a private 4 KB
+// of LDS, 32 tokens x 64 features at a time: + bias (fp32, before the single rounding), SiLU on whole 32-feature blocks,
+// packed 8-byte writes (16-byte slot ^= (token >> 1) & 7: conflict-free), 16-byte reads; every global store instruction then
+// covers 8 tokens x 128 contiguous bytes.  `s_bias`: the bias vector staged in LDS as bf16 (or nullptr).
+template <int MB, int NB>
+__device__ __forceinline__ void linear_epilogue(const f32x16 (&acc)[NB][MB], unsigned char *scr, const uint16_t *s_bias,
+                                                const rsrc_t o_rs, const int64_t o_pitch, const int n_wave0, const int silu_from_col,
+                                                const int lane) {
+    const int j = lane & 31, kh = lane >> 5;
+    const int wr_off = j * 128 + kh * 8, wr_sw = (j >> 1) & 7;                               // this lane's row in the scratch tile
+    const int rd_tok = lane >> 3, rd_slot = (lane & 7) ^ (rd_tok >> 1);                      // row = i * 8 + rd_tok: swizzle (row >> 1) & 7
+    const unsigned st_off = static_cast<unsigned>(rd_tok * o_pitch + (lane & 7) * 16);
+    const unsigned scr_lds = static_cast<unsigned>(reinterpret_cast<uintptr_t>((lds_ptr_t)(scr)));      // LDS byte address
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb) {
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+            const int n0 = n_wave0 + nb * 32;                                                  // wave-uniform
+            float v[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) v[r] = acc[nb][mb][r];
+            if (s_bias) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const uint2 bq = *reinterpret_cast<const uint2 *>(s_bias + n0 + 4 * kh + q * 8);
+                    v[q * 4 + 0] += __uint_as_float(bq.x << 16);
+                    v[q * 4 + 1] += __uint_as_float(bq.x & 0xffff0000u);
+                    v[q * 4 + 2] += __uint_as_float(bq.y << 16);
+                    v[q * 4 + 3] += __uint_as_float(bq.y & 0xffff0000u);
+                }
+            }
+            if (n0 >= silu_from_col) {                                                         // (silu_from_col % 32 == 0)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) v[r] = silu(v[r]);
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                uint2 pk;
+                pk.x = static_cast<uint32_t>(from_float<BF16>(v[q * 4])) | (static_cast<uint32_t>(from_float<BF16>(v[q * 4 + 1])) << 16);
+                pk.y = static_cast<uint32_t>(from_float<BF16>(v[q * 4 + 2])) | (static_cast<uint32_t>(from_float<BF16>(v[q * 4 + 3])) << 16);
+                // (inline asm: a ds_write the compiler can see makes it drain vmcnt — i.e. the whole load ring — first,
+                // because an LDS-DMA in flight might target the same bytes; it cannot: the scratch is outside the ring)
+                typedef unsigned u2 __attribute__((ext_vector_type(2)));
+                const u2 pkv = {pk.x, pk.y};
+                asm volatile("ds_write_b64 %0, %1" ::"v"(scr_lds + wr_off + (((nb * 4 + q) ^ wr_sw) << 4)), "v"(pkv) : "memory");
+            }
+        }
+        // wave-private scratch: writes and reads of one wave execute in order in the LDS; the reads' data is waited for below
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            typedef unsigned u4 __attribute__((ext_vector_type(4)));
+            const u4 row = *reinterpret_cast<const u4 *>(scr + i * 1024 + rd_tok * 128 + ((rd_slot ^ ((i & 1) << 2)) << 4));
+            __builtin_amdgcn_raw_buffer_store_b128(row, o_rs, st_off, static_cast<int>((mb * 32 + i * 8) * o_pitch), 0);
+        }
+    }
+}
+
+template <int WN_, bool HAS_BIAS>
+__global__ __launch_bounds__(512, 2) void linear_tn_kernel(const zigma_linear_params_t p, const int tiles_m, const int tiles_n) {
+    constexpr int BM = kLinBM, BN = 64 * WN_, WM_ = 8 / WN_, MB = BM / WM_ / 32, NB = 2;
+    constexpr int ROWS = BN + BM, STAGE = ROWS * 128;            // bytes per stage: W rows first, then token rows
+    constexpr int NLD = ROWS / 64;                                 // direct-to-LDS loads per wave per stage (8 rows each)
+    // ONE LDS object (a second one makes hipcc drain vmcnt in front of every fragment read, cdna_hip_programming.md §5):
+    // [2 stages][bias as bf16, n <= 16384]
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[2 * STAGE + (HAS_BIAS ? 32768 : 0)];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wn = wave % WN_, wm = wave / WN_;
+    const int j = lane & 31, kh = lane >> 5;
+    const int nk = p.k / kLinBK;
+    const unsigned char *xb = reinterpret_cast<const unsigned char *>(p.x);
+    const unsigned char *wb = reinterpret_cast<const unsigned char *>(p.w);
+    const int64_t x_pitch = p.x_row_stride * 2, w_pitch = p.w_row_stride * 2;
+
+    // ---- tile schedule: XCD x owns the contiguous raster chunk [x * chunk, (x + 1) * chunk); its workgroups take it round-robin
+    const int n_tiles = tiles_m * tiles_n;
+    const int xcd = blockIdx.x & 7, slot_in_xcd = blockIdx.x >> 3, wg_per_xcd = gridDim.x >> 3;
+    const int chunk = (n_tiles + 7) >> 3;
+    const int chunk_end = (xcd + 1) * chunk < n_tiles ? (xcd + 1) * chunk : n_tiles;
+    int tile = xcd * chunk + slot_in_xcd;
+    if (tile >= chunk_end) return;
+
+    // staging pattern.  Direct-to-LDS instruction i of wave w fills the 8 rows q*8 .. q*8+7, q = i * 8 + w, of the stage: rows
+    // [0, BN) are W rows, [BN, BN + 256) token rows, so the operand of instruction i is known at compile time (i < BN / 64).
+    // Per lane the source address is
+    //   operand base (SGPR) + [tile row0 + i' * 64] * pitch + kt * 128                     (wave-uniform: scalar unit)
+    //   + (w * 8 + (lane >> 3)) * pitch + piece * 16,  piece = (lane & 7) ^ ((row >> 1) & 7)  (per lane, ONE value per operand)
+    // with row = w * 8 + (lane >> 3) (mod 16): the swizzle term does not depend on i.
+    const int srow = wave * 8 + (lane >> 3);
+    const unsigned piece = ((lane & 7) ^ ((srow >> 1) & 7)) << 4;
+    const unsigned lane_off_w = static_cast<unsigned>(srow * w_pitch) + piece, lane_off_x = static_cast<unsigned>(srow * x_pitch) + piece;
+    const int dbg = p.flags;
+    auto stage = [&](int buf, int t, int kt) {
+        const int mt = t / tiles_n, nt = t - mt * tiles_n;
+        const unsigned char *wbase = wb + static_cast<int64_t>(nt) * BN * w_pitch + kt * (kLinBK * 2);
+        const unsigned char *xbase = xb + static_cast<int64_t>(mt) * BM * x_pitch + kt * (kLinBK * 2);
+        const int64_t rows_left = p.m - static_cast<int64_t>(mt) * BM;      // m % 8 == 0: a group of 8 rows exists or does not
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) {
+            const unsigned char *src;
+            if (i < BN / 64) {
+                src = wbase + static_cast<int64_t>(i * 64) * w_pitch + lane_off_w;
+            } else {
+                const int r0 = (i - BN / 64) * 64;
+                src = xbase + (r0 + wave * 8 < rows_left ? static_cast<int64_t>(r0) * x_pitch : -static_cast<int64_t>(wave * 8) * x_pitch) + lane_off_x;
+            }
+            __builtin_amdgcn_global_load_lds((gbl_ptr_t)(src), (lds_ptr_t)(smem) + buf * STAGE + (i * 8 + wave) * 1024, 16, 0, 0);
+        }
+    };
+
+    // fragment read offsets: row * 128 + (((ks << 1) | kh) ^ ((row >> 1) & 7)) * 16, row = base (multiple of 32) + j
+    const int sw = (j >> 1) & 7;
+    const int a_row0 = (wn * 64 + j) * 128, b_row0 = (BN + wm * (BM / WM_) + j) * 128;
+
+    if (HAS_BIAS) {                                                // before the first direct-to-LDS load; visible to all after the first barrier
+        for (int i = tid; i < p.n / 2; i += 512)
+            reinterpret_cast<uint32_t *>(smem + 2 * STAGE)[i] = reinterpret_cast<const uint32_t *>(p.bias)[i];
+    }
+    int buf = 0;
+    stage(0, tile, 0);
+#pragma unroll 1
+    while (true) {
+        const int next = tile + wg_per_xcd;
+        const bool has_next = next < chunk_end;
+        f32x16 acc[NB][MB];
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+            for (int mb = 0; mb < MB; ++mb) acc[nb][mb] = f32x16{};
+#pragma unroll 1
+        for (int kt = 0; kt < nk; ++kt) {
+            __syncthreads();                // stage `buf` has landed (vmcnt(0) before the barrier); stage buf^1 is free again
+            if (!(dbg & 0x200)) {
+                if (kt + 1 < nk) stage(buf ^ 1, tile, kt + 1);
+                else if (has_next) stage(buf ^ 1, next, 0);
+            }
+            const unsigned char *sb = smem + buf * STAGE;
+            // fragments one k-substep ahead of the MFMAs that use them (the LDS latency hides under the previous 8 MFMAs)
+            bf16x8 a[2][NB], b[2][MB];
+            auto frags = [&](int ks, bf16x8 (&fa)[NB], bf16x8 (&fb)[MB]) {
+                const int off = ((((ks << 1) | kh) ^ sw) << 4);
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb)
+                    fa[nb] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4 *>(sb + a_row0 + nb * 32 * 128 + off));
+#pragma unroll
+                for (int mb = 0; mb < MB; ++mb)
+                    fb[mb] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4 *>(sb + b_row0 + mb * 32 * 128 + off));
+            };
+            if (dbg & 0x100) { buf ^= 1; continue; }
+            frags(0, a[0], b[0]);
+#pragma unroll
+            for (int ks = 0; ks < kLinBK / 16; ++ks) {
+                if (ks + 1 < kLinBK / 16) frags(ks + 1, a[(ks + 1) & 1], b[(ks + 1) & 1]);
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+                    for (int mb = 0; mb < MB; ++mb)
+                        acc[nb][mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ks & 1][nb], b[ks & 1][mb], acc[nb][mb], 0, 0, 0);
+            }
+            // Pin the order hipcc would otherwise collapse to [all reads of a sub-step -> wait -> its MFMAs]: the NB + MB reads of
+            // sub-step ks + 1 are issued one by one between the first MFMAs of sub-step ks (masks: 0x100 DS read, 0x008 MFMA).
+            {
+                __builtin_amdgcn_sched_group_barrier(0x100, NB + MB, 0);
+#pragma unroll
+                for (int ks = 0; ks + 1 < kLinBK / 16; ++ks) {
+#pragma unroll
+                    for (int r = 0; r < NB + MB; ++r) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                    }
+                    __builtin_amdgcn_sched_group_barrier(0x008, NB * MB - (NB + MB), 0);
+                }
+                __builtin_amdgcn_sched_group_barrier(0x008, NB * MB, 0);
+            }
+            buf ^= 1;
+        }
+        // ---- epilogue: transposed through the stage the main loop has just finished with ----------------------------------------
+        if (!(dbg & 0x400)) {
+            __syncthreads();                                                                  // every wave is done with the fragments of this stage
+            const int mt = tile / tiles_n, nt = tile - mt * tiles_n;
+            const int64_t m_tile = static_cast<int64_t>(mt) * BM + wm * (BM / WM_);           // first token of this wave's tile
+            const int64_t rows_here = p.m - m_tile;                                            // tokens of it that exist
+            const int64_t o_pitch = p.out_row_stride * 2;
+            // rows as buffer descriptor (base = the wave tile's first row and first column, extent = its valid rows): stores of
+            // tokens beyond m fall outside the extent and are dropped by the hardware
+            const rsrc_t o_rs = make_rsrc(reinterpret_cast<unsigned char *>(p.out) + m_tile * o_pitch + (nt * BN + wn * 64) * 2,
+                                          rows_here > 0 ? (rows_here < BM / WM_ ? rows_here : BM / WM_) * o_pitch - (nt * BN + wn * 64) * 2 : 0);
+            linear_epilogue<MB, NB>(acc, smem + (buf ^ 1) * STAGE + wave * 4096,
+                                    HAS_BIAS ? reinterpret_cast<const uint16_t *>(smem + 2 * STAGE) : nullptr, o_rs, o_pitch, nt * BN + wn * 64,
+                                    p.silu_from_col, lane);                                   // (buf already points at the next stage)
+        }
+        if (!has_next) break;
+        tile = next;
+    }
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// Third arrangement: TWO workgroups per CU.  128 tokens x 256 features per workgroup, 4 waves (one per SIMD, wave tile 64 x 128 as
+// in the 256 x 256 kernel), BK = 32, two 24 KB stages -> 48 KB of LDS and <= 256 VGPRs per wave, so two workgroups share a CU.
+// The first pipeline's loss is structural: one workgroup per CU means every wave of the CU waits at the same barrier, loads
+// are exposed whenever they take longer than one k-step, and nothing runs during the epilogue's stores.  Two independent
+// workgroups per CU interleave on their own (the CU's other workgroup issues MFMAs while this one waits or stores), at the
+// price of 1.5 x the L2 -> LDS traffic per flop (128 x 256 instead of 256 x 256 tiles).
+template <bool HAS_BIAS>
+__global__ __launch_bounds__(256, 2) void linear_tn3_kernel(const zigma_linear_params_t p, const int tiles_m, const int tiles_n) {
+    constexpr int BM = 128, BN = 256, BK = 32, MB = 4, NB = 2;
+    constexpr int ROWS = BN + BM, STAGE = ROWS * BK * 2;         // 24 KB per stage: W rows first, then token rows (64 B each)
+    constexpr int NLD = STAGE / 1024 / 4;                          // 6 direct-to-LDS loads per wave per stage (16 rows x 64 B each)
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[2 * STAGE + (HAS_BIAS ? 32768 : 0)];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // = n position of the wave tile (4 x 64 features)
+    const int j = lane & 31, kh = lane >> 5;
+    const int nk = p.k / BK;
+    const unsigned char *xb = reinterpret_cast<const unsigned char *>(p.x);
+    const unsigned char *wb = reinterpret_cast<const unsigned char *>(p.w);
+    const int64_t x_pitch = p.x_row_stride * 2, w_pitch = p.w_row_stride * 2;
+
+    const int n_tiles = tiles_m * tiles_n;
+    const int xcd = blockIdx.x & 7, slot_in_xcd = blockIdx.x >> 3, wg_per_xcd = gridDim.x >> 3;
+    const int chunk = (n_tiles + 7) >> 3;
+    const int chunk_end = (xcd + 1) * chunk < n_tiles ? (xcd + 1) * chunk : n_tiles;
+    int tile = xcd * chunk + slot_in_xcd;
+    if (tile >= chunk_end) return;
+
+    // staging: instruction i of wave w fills rows q*16 .. q*16+15 of a stage, q = i * 4 + w (W rows first: i < 4);
+    // lane -> row (lane >> 2), 16-byte slot (lane & 3) holding source piece (lane & 3) ^ ((row >> 2) & 3)
+    const int srow = wave * 16 + (lane >> 2);
+    const unsigned piece = ((lane & 3) ^ ((lane >> 4) & 3)) << 4;
+    const unsigned lane_off_w = static_cast<unsigned>(srow * w_pitch) + piece, lane_off_x = static_cast<unsigned>(srow * x_pitch) + piece;
+    auto stage = [&](int buf, int t, int kt) {
+        const int mt = t / tiles_n, nt = t - mt * tiles_n;
+        const unsigned char *wbase = wb + static_cast<int64_t>(nt) * BN * w_pitch + kt * (BK * 2);
+        const unsigned char *xbase = xb + static_cast<int64_t>(mt) * BM * x_pitch + kt * (BK * 2);
+        const int64_t rows_left = p.m - static_cast<int64_t>(mt) * BM;      // m % 16 == 0: a group of 16 rows exists or does not
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) {
+            const unsigned char *src;
+            if (i < BN / 64) {
+                src = wbase + static_cast<int64_t>(i * 64) * w_pitch + lane_off_w;
+            } else {
+                const int r0 = (i - BN / 64) * 64;
+                src = xbase + (r0 + wave * 16 < rows_left ? static_cast<int64_t>(r0) * x_pitch : -static_cast<int64_t>(wave * 16) * x_pitch) + lane_off_x;
+            }
+            __builtin_amdgcn_global_load_lds((gbl_ptr_t)(src), (lds_ptr_t)(smem) + buf * STAGE + (i * 4 + wave) * 1024, 16, 0, 0);
+        }
+    };
+    // fragment reads: row * 64 + ((ksub * 2 + kh) ^ ((row >> 2) & 3)) * 16, row = base (multiple of 32) + j
+    const int sw = (j >> 2) & 3;
+    const int a_row0 = (wave * 64 + j) * 64, b_row0 = (BN + j) * 64;
+    const int off0 = ((kh ^ sw) << 4), off1 = (((2 | kh) ^ sw) << 4);
+
+    if (HAS_BIAS) {
+        for (int i = tid; i < p.n / 2; i += 256)
+            reinterpret_cast<uint32_t *>(smem + 2 * STAGE)[i] = reinterpret_cast<const uint32_t *>(p.bias)[i];
+    }
+    int buf = 0;
+    stage(0, tile, 0);
+#pragma unroll 1
+    while (true) {
+        const int next = tile + wg_per_xcd;
+        const bool has_next = next < chunk_end;
+        f32x16 acc[NB][MB];
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+            for (int mb = 0; mb < MB; ++mb) acc[nb][mb] = f32x16{};
+#pragma unroll 1
+        for (int kt = 0; kt < nk; ++kt) {
+            __syncthreads();
+            if (kt + 1 < nk) stage(buf ^ 1, tile, kt + 1);
+            else if (has_next) stage(buf ^ 1, next, 0);
+            const unsigned char *sb = smem + buf * STAGE;
+            bf16x8 a[2][NB], b[2][MB];
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                const int off = ks ? off1 : off0;
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb)
+                    a[ks][nb] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4 *>(sb + a_row0 + nb * 32 * 64 + off));
+#pragma unroll
+                for (int mb = 0; mb < MB; ++mb)
+                    b[ks][mb] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4 *>(sb + b_row0 + mb * 32 * 64 + off));
+            }
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+                    for (int mb = 0; mb < MB; ++mb)
+                        acc[nb][mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ks][nb], b[ks][mb], acc[nb][mb], 0, 0, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, NB + MB, 0);       // reads of sub-step 1 between the MFMAs of sub-step 0
+#pragma unroll
+            for (int r = 0; r < NB + MB; ++r) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            }
+            __builtin_amdgcn_sched_group_barrier(0x008, 2 * NB * MB - (NB + MB), 0);
+            buf ^= 1;
+        }
+        if (!(p.flags & 0x400)) {
+            __syncthreads();                                                                  // every wave is done with the fragments of this stage
+            const int mt = tile / tiles_n, nt = tile - mt * tiles_n;
+            const int64_t m_tile = static_cast<int64_t>(mt) * BM;
+            const int64_t rows_here = p.m - m_tile;
+            const int64_t o_pitch = p.out_row_stride * 2;
+            const rsrc_t o_rs = make_rsrc(reinterpret_cast<unsigned char *>(p.out) + m_tile * o_pitch + (nt * BN + wave * 64) * 2,
+                                          rows_here > 0 ? (rows_here < BM ? rows_here : BM) * o_pitch - (nt * BN + wave * 64) * 2 : 0);
+            linear_epilogue<MB, NB>(acc, smem + (buf ^ 1) * STAGE + wave * 4096,
+                                    HAS_BIAS ? reinterpret_cast<const uint16_t *>(smem + 2 * STAGE) : nullptr, o_rs, o_pitch, nt * BN + wave * 64,
+                                    p.silu_from_col, lane);
+        }
+        if (!has_next) break;
+        tile = next;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// Second pipeline: the same tiles, fragments and epilogue, but the k-loop runs in HALF steps of 32 columns through a ring of
+// four 32-column LDS slots, with loads issued three half-steps (1.5 k-steps) ahead and a COUNTED s_waitcnt vmcnt (never 0 in
+// steady state) in front of a raw s_barrier: measured on the first pipeline, one k-step of MFMAs (~1.5 us at the clock this
+// kernel sustains) does not cover the latency of the loads issued one k-step ahead (~1 us for 64 KB per CU with every CU
+// asking at once), and __syncthreads() drains the direct-to-LDS queue at every step.  The epilogue transposes through a
+// dedicated 32 KB scratch area (no barrier: wave-private), so the ring keeps running across tile boundaries; its stores share
+// the vmcnt counter with the loads, which only makes the counted waits conservative (loads return in order among loads).
+template <int WN_, bool HAS_BIAS>
+__global__ __launch_bounds__(512, 2) void linear_tn2_kernel(const zigma_linear_params_t p, const int tiles_m, const int tiles_n) {
+    constexpr int BM = kLinBM, BN = 64 * WN_, WM_ = 8 / WN_, MB = BM / WM_ / 32, NB = 2;
+    constexpr int ROWS = BN + BM, HSLOT = ROWS * 64;             // bytes per ring slot: ROWS rows x 32 bf16
+    constexpr int NLDH = ROWS / 128;                               // direct-to-LDS loads per wave per slot (16 rows x 64 B each)
+    constexpr int SCR = 4 * HSLOT;
+    static_assert(!HAS_BIAS || WN_ == 2, "the bias vector is staged in the LDS the 256 x 128 tile leaves free");
+    // ONE LDS object (a second one makes hipcc drain vmcnt in front of every fragment read, cdna_hip_programming.md §5):
+    // [4 ring slots][8 x 4 KB epilogue scratch][bias, bf16, n <= 16384]
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[4 * HSLOT + 8 * 4096 + (HAS_BIAS ? 32768 : 0)];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wn = wave % WN_, wm = wave / WN_;
+    const int j = lane & 31, kh = lane >> 5;
+    const int nk = p.k / kLinBK;
+    const unsigned char *xb = reinterpret_cast<const unsigned char *>(p.x);
+    const unsigned char *wb = reinterpret_cast<const unsigned char *>(p.w);
+    const int64_t x_pitch = p.x_row_stride * 2, w_pitch = p.w_row_stride * 2;
+
+    const int n_tiles = tiles_m * tiles_n;
+    const int xcd = blockIdx.x & 7, slot_in_xcd = blockIdx.x >> 3, wg_per_xcd = gridDim.x >> 3;
+    const int chunk = (n_tiles + 7) >> 3;
+    const int chunk_end = (xcd + 1) * chunk < n_tiles ? (xcd + 1) * chunk : n_tiles;
+    const int tile0 = xcd * chunk + slot_in_xcd;
+    if (tile0 >= chunk_end) return;
+    const int my_tiles = (chunk_end - tile0 + wg_per_xcd - 1) / wg_per_xcd;
+    const int h_total = my_tiles * nk * 2;                         // half-steps of this workgroup's whole run
+
+    // staging: instruction i of wave w fills rows q*16 .. q*16+15 of a slot, q = i * 8 + w (W rows first: i < BN / 128);
+    // lane -> row (lane >> 2), 16-byte slot (lane & 3) holding source piece (lane & 3) ^ ((row >> 2) & 3)
+    const int srow = wave * 16 + (lane >> 2);
+    const unsigned piece = ((lane & 3) ^ ((lane >> 4) & 3)) << 4;
+    const unsigned lane_off_w = static_cast<unsigned>(srow * w_pitch) + piece, lane_off_x = static_cast<unsigned>(srow * x_pitch) + piece;
+    int is_tile = tile0, is_kt = 0, is_half = 0, is_h = 0;         // issue cursor
+    auto issue = [&]() {
+        const int mt = is_tile / tiles_n, nt = is_tile - mt * tiles_n;
+        const int koff = is_kt * (kLinBK * 2) + is_half * 64;
+        const unsigned char *wbase = wb + static_cast<int64_t>(nt) * BN * w_pitch + koff;
+        const unsigned char *xbase = xb + static_cast<int64_t>(mt) * BM * x_pitch + koff;
+        const int64_t rows_left = p.m - static_cast<int64_t>(mt) * BM;  // m % 16 == 0: a group of 16 rows exists or does not
+        unsigned char *dst = smem + (is_h & 3) * HSLOT;
+#pragma unroll
+        for (int i = 0; i < NLDH; ++i) {
+            const unsigned char *src;
+            if (i < BN / 128) {
+                src = wbase + static_cast<int64_t>(i * 128) * w_pitch + lane_off_w;
+            } else {
+                const int r0 = (i - BN / 128) * 128;
+                src = xbase + (r0 + wave * 16 < rows_left ? static_cast<int64_t>(r0) * x_pitch : -static_cast<int64_t>(wave * 16) * x_pitch) + lane_off_x;
+            }
+            __builtin_amdgcn_global_load_lds((gbl_ptr_t)(src), (lds_ptr_t)(dst) + (i * 8 + wave) * 1024, 16, 0, 0);
+        }
+        ++is_h;
+        if (++is_half == 2) { is_half = 0; if (++is_kt == nk) { is_kt = 0; is_tile += wg_per_xcd; } }
+    };
+
+    // fragment reads: row * 64 + ((ksub * 2 + kh) ^ ((row >> 2) & 3)) * 16, row = base (multiple of 32) + j
+    const int sw = (j >> 2) & 3;
+    const int a_row0 = (wn * 64 + j) * 64, b_row0 = (BN + wm * (BM / WM_) + j) * 64;
+    const int off0 = ((kh ^ sw) << 4), off1 = (((2 | kh) ^ sw) << 4);
+
+    if (HAS_BIAS) {                                                // visible to every wave after the first barrier of the ring
+        for (int i = tid; i < p.n / 2; i += 512)
+            reinterpret_cast<uint32_t *>(smem + SCR + 8 * 4096)[i] = reinterpret_cast<const uint32_t *>(p.bias)[i];
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // (plain loads: off the counter before the ring starts counting)
+    }
+#pragma unroll 1
+    for (int h = 0; h < 3 && h < h_total; ++h) issue();
+
+    int g = 0;
+    int tile = tile0;
+#pragma unroll 1
+    for (int ti = 0; ti < my_tiles; ++ti, tile += wg_per_xcd) {
+        f32x16 acc[NB][MB];
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+            for (int mb = 0; mb < MB; ++mb) acc[nb][mb] = f32x16{};
+#pragma unroll 1
+        for (int hs = 0; hs < 2 * nk; ++hs, ++g) {
+            // the slot of half-step g has landed when at most the two younger batches are still in flight
+            const int rem = h_total - 1 - g;
+            if (rem >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NLDH) : "memory");
+            else if (rem == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NLDH) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();                       // ... for every wave; and every wave is done reading slot g - 1
+            if (g + 3 < h_total) issue();                        // refill slot (g + 3) & 3 == (g - 1) & 3
+            const unsigned char *sb = smem + (g & 3) * HSLOT;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                const int off = ks ? off1 : off0;
+                bf16x8 a[NB], b[MB];
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb)
+                    a[nb] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4 *>(sb + a_row0 + nb * 32 * 64 + off));
+#pragma unroll
+                for (int mb = 0; mb < MB; ++mb)
+                    b[mb] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4 *>(sb + b_row0 + mb * 32 * 64 + off));
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+                    for (int mb = 0; mb < MB; ++mb)
+                        acc[nb][mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[nb], b[mb], acc[nb][mb], 0, 0, 0);
+            }
+        }
+        // ---- epilogue: scratch is a dedicated wave-private 4 KB, so no barrier and the ring keeps running ---------------------
+        if (!(p.flags & 0x400)) {
+            const int mt = tile / tiles_n, nt = tile - mt * tiles_n;
+            const int64_t m_tile = static_cast<int64_t>(mt) * BM + wm * (BM / WM_);
+            const int64_t rows_here = p.m - m_tile;
+            const int64_t o_pitch = p.out_row_stride * 2;
+            const rsrc_t o_rs = make_rsrc(reinterpret_cast<unsigned char *>(p.out) + m_tile * o_pitch + (nt * BN + wn * 64) * 2,
+                                          rows_here > 0 ? (rows_here < BM / WM_ ? rows_here : BM / WM_) * o_pitch - (nt * BN + wn * 64) * 2 : 0);
+            linear_epilogue<MB, NB>(acc, smem + SCR + wave * 4096, HAS_BIAS ? reinterpret_cast<const uint16_t *>(smem + SCR + 8 * 4096) : nullptr,
+                                    o_rs, o_pitch, nt * BN + wn * 64, p.silu_from_col, lane);
+        }
+    }
+}
+
+}  // namespace zigma
+
+using namespace zigma;
+
+extern "C" int zigma_linear_fwd(const zigma_linear_params_t *pp, void *stream_) {
+    if (!pp) return ZIGMA_ERR_NULL;
+    (void)hipGetLastError();
+    const zigma_linear_params_t &p = *pp;
+    if (p.m < 0 || p.n < 1 || p.k < 1) return ZIGMA_ERR_SHAPE;
+    if (p.flags & ~0x7f00) return ZIGMA_ERR_UNSUPPORTED;     // 0x100 ... 0x1000: timing / A-B probes (tools/linear_probe.py)
+    if (p.m == 0) return ZIGMA_OK;
+    if (!p.x || !p.w || !p.out) return ZIGMA_ERR_NULL;
+    if (p.dtype != ZIGMA_BF16) return ZIGMA_ERR_DTYPE;
+    if (p.k % kLinBK != 0 || p.n % 128 != 0 || p.m % 8 != 0) return ZIGMA_ERR_SHAPE;
+    if (p.m * p.x_row_stride * 2 > 0x7fffffff || static_cast<int64_t>(p.n) * p.w_row_stride * 2 > 0x7fffffff ||
+        256 * p.out_row_stride * 2 > 0x7fffffff)
+        return ZIGMA_ERR_SHAPE;                       // 32-bit lane offsets inside an operand tile / a wave's output rows
+    if (p.silu_from_col < 0 || p.silu_from_col % 32 != 0) return ZIGMA_ERR_SHAPE;
+    if (p.x_row_stride % 8 != 0 || p.w_row_stride % 8 != 0 || p.out_row_stride % 4 != 0 ||
+        (reinterpret_cast<uintptr_t>(p.x) | reinterpret_cast<uintptr_t>(p.w)) % 16 != 0 || reinterpret_cast<uintptr_t>(p.out) % 8 != 0)
+        return ZIGMA_ERR_STRIDE;
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    const int tiles_m = static_cast<int>((p.m + kLinBM - 1) / kLinBM);
+    // 0x1000: force the 256 x 128 tile (probe).
+    const bool ring = (p.flags & 0x800) && p.m % 16 == 0;         // 0x800: the half-step ring pipeline (measured slower: A/B probe only)
+    const bool wide = p.n % 256 == 0 && !(p.flags & 0x1000) && !(ring && p.bias);
+    if (p.bias && (p.n > 16384 || reinterpret_cast<uintptr_t>(p.bias) % 4 != 0)) return ZIGMA_ERR_SHAPE;
+    const int tiles_n = p.n / (wide ? 256 : 128);
+    const int64_t n_tiles = static_cast<int64_t>(tiles_m) * tiles_n;
+    if (n_tiles > 0x7fffffff) return ZIGMA_ERR_SHAPE;
+    int grid = 256;                                  // one persistent workgroup per CU; multiples of 8 keep the XCD map
+    if (n_tiles < grid) grid = static_cast<int>((n_tiles + 7) / 8 * 8);
+    if ((p.flags & 0x2000) && p.n % 256 == 0 && p.m % 16 == 0) {        // 0x2000: two workgroups per CU, 128 x 256 tiles
+        const int tm = static_cast<int>((p.m + 127) / 128), tn = p.n / 256;
+        const int64_t nt3 = static_cast<int64_t>(tm) * tn;
+        if (nt3 > 0x7fffffff) return ZIGMA_ERR_SHAPE;
+        int g3 = 512;
+        if (nt3 < g3) g3 = static_cast<int>((nt3 + 7) / 8 * 8);
+        if (p.bias) hipLaunchKernelGGL((linear_tn3_kernel<true>), dim3(g3), dim3(256), 0, stream, p, tm, tn);
+        else hipLaunchKernelGGL((linear_tn3_kernel<false>), dim3(g3), dim3(256), 0, stream, p, tm, tn);
+        set_last_kernel("linear_tn3_128x256");
+        return check_launch();
+    }
+    if (ring) {
+        if (wide) hipLaunchKernelGGL((linear_tn2_kernel<4, false>), dim3(grid), dim3(512), 0, stream, p, tiles_m, tiles_n);
+        else if (p.bias) hipLaunchKernelGGL((linear_tn2_kernel<2, true>), dim3(grid), dim3(512), 0, stream, p, tiles_m, tiles_n);
+        else hipLaunchKernelGGL((linear_tn2_kernel<2, false>), dim3(grid), dim3(512), 0, stream, p, tiles_m, tiles_n);
+        set_last_kernel(wide ? "linear_tn2_256x256" : "linear_tn2_256x128");
+        return check_launch();
+    }
+
+    if (wide) {
+        if (p.bias) hipLaunchKernelGGL((linear_tn_kernel<4, true>), dim3(grid), dim3(512), 0, stream, p, tiles_m, tiles_n);
+        else hipLaunchKernelGGL((linear_tn_kernel<4, false>), dim3(grid), dim3(512), 0, stream, p, tiles_m, tiles_n);
+    } else {
+        if (p.bias) hipLaunchKernelGGL((linear_tn_kernel<2, true>), dim3(grid), dim3(512), 0, stream, p, tiles_m, tiles_n);
+        else hipLaunchKernelGGL((linear_tn_kernel<2, false>), dim3(grid), dim3(512), 0, stream, p, tiles_m, tiles_n);
+    }
+    set_last_kernel(wide ? "linear_tn_256x256" : "linear_tn_256x128");
+    return check_launch();
+}

@@ -10,7 +10,10 @@ x = torch.randn(65536, 640, device="cuda", dtype=torch.bfloat16); w = (torch.ran
 for _ in range(10): linear(x, w, None, 1280)
 torch.cuda.synchronize()
 PY
-for pass in "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum" "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_INSTS_VALU"; do
+PASSES=("TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum" "FETCH_SIZE" "WRITE_SIZE"
+        "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_INSTS_VALU"
+        "SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_LDS_ADDR_CONFLICT SQ_LDS_UNALIGNED_STALL SQ_INSTS_VMEM")
+for pass in "${PASSES[@]}"; do
   tag=$(echo $pass | cut -d' ' -f1)
   timeout 120 rocprofv3 --pmc $pass --output-format csv -d $R/gpurun_out/pmcl_$tag -o pmc -- python /tmp/lin_one.py > $R/gpurun_out/pmcl_$tag.log 2>&1
 done

@@ -95,14 +95,37 @@ __device__ __forceinline__ void linear_epilogue(const f32x16 (&acc)[NB][MB], uns
     }
 }
 
-template <int WN_, bool HAS_BIAS>
+// s_waitcnt vmcnt(n) for the handful of counts the pipeline uses (the instruction takes an immediate)
+__device__ __forceinline__ void wait_vm(int n) {
+    switch (n) {
+        case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+        case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+        case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+        case 14: asm volatile("s_waitcnt vmcnt(14)" ::: "memory"); break;
+        case 16: asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); break;
+        default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+    }
+}
+
+// WN_ = waves along the features: 4 -> 256 x 256 tile (wave tile 64 x 128), 2 -> 256 x 128 tile (wave tile 64 x 64).
+// NST = LDS stages of one k-step each: the k-steps of ALL tiles of the workgroup form one pipeline, loads run NST - 1 k-steps
+// ahead (two stages of 64 KB for the wide tile; the narrow tile's 48 KB stages leave room for a third, which is what makes
+// out_proj insensitive to where its operand lives — inside the forward its input was just written by the scan).
+// Synchronisation is explicit: ONE raw s_barrier per k-step behind a COUNTED s_waitcnt vmcnt.  VM_CNT retires in issue order
+// for loads and stores alike on gfx9-class targets (the compiler's own wait insertion relies on it), so the count is "what
+// was issued after the batch this k-step needs": the younger load batch (NST == 3) and, during the first NST - 1 k-steps
+// after an epilogue, that epilogue's stores — the store acknowledgements are never waited for on the critical path
+// (__syncthreads() would drain them: measured ~2 us per tile).
+template <int WN_, int NST, bool HAS_BIAS>
 __global__ __launch_bounds__(512, 2) void linear_tn_kernel(const zigma_linear_params_t p, const int tiles_m, const int tiles_n) {
     constexpr int BM = kLinBM, BN = 64 * WN_, WM_ = 8 / WN_, MB = BM / WM_ / 32, NB = 2;
     constexpr int ROWS = BN + BM, STAGE = ROWS * 128;            // bytes per stage: W rows first, then token rows
     constexpr int NLD = ROWS / 64;                                 // direct-to-LDS loads per wave per stage (8 rows each)
-    // ONE LDS object (a second one makes hipcc drain vmcnt in front of every fragment read, cdna_hip_programming.md §5):
-    // [2 stages][bias as bf16, n <= 16384]
-    __shared__ __attribute__((aligned(1024))) unsigned char smem[2 * STAGE + (HAS_BIAS ? 32768 : 0)];
+    constexpr int NSTORE = MB * 4;                                 // 16-byte stores per wave per epilogue
+    constexpr int BIAS_BYTES = HAS_BIAS ? 8192 : 0;                // n <= 4096
+    static_assert(NST * STAGE + BIAS_BYTES <= 160 * 1024, "LDS");
+    // ONE LDS object (a second one makes hipcc drain vmcnt in front of every fragment read, cdna_hip_programming.md §5)
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[NST * STAGE + BIAS_BYTES];
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -112,14 +135,17 @@ __global__ __launch_bounds__(512, 2) void linear_tn_kernel(const zigma_linear_pa
     const unsigned char *xb = reinterpret_cast<const unsigned char *>(p.x);
     const unsigned char *wb = reinterpret_cast<const unsigned char *>(p.w);
     const int64_t x_pitch = p.x_row_stride * 2, w_pitch = p.w_row_stride * 2;
+    const int dbg = p.flags;
 
     // ---- tile schedule: XCD x owns the contiguous raster chunk [x * chunk, (x + 1) * chunk); its workgroups take it round-robin
     const int n_tiles = tiles_m * tiles_n;
     const int xcd = blockIdx.x & 7, slot_in_xcd = blockIdx.x >> 3, wg_per_xcd = gridDim.x >> 3;
     const int chunk = (n_tiles + 7) >> 3;
     const int chunk_end = (xcd + 1) * chunk < n_tiles ? (xcd + 1) * chunk : n_tiles;
-    int tile = xcd * chunk + slot_in_xcd;
-    if (tile >= chunk_end) return;
+    const int tile0 = xcd * chunk + slot_in_xcd;
+    if (tile0 >= chunk_end) return;
+    const int my_tiles = (chunk_end - tile0 + wg_per_xcd - 1) / wg_per_xcd;
+    const int g_total = my_tiles * nk;                             // k-steps of this workgroup's whole run
 
     // staging pattern.  Direct-to-LDS instruction i of wave w fills the 8 rows q*8 .. q*8+7, q = i * 8 + w, of the stage: rows
     // [0, BN) are W rows, [BN, BN + 256) token rows, so the operand of instruction i is known at compile time (i < BN / 64).
@@ -130,12 +156,13 @@ __global__ __launch_bounds__(512, 2) void linear_tn_kernel(const zigma_linear_pa
     const int srow = wave * 8 + (lane >> 3);
     const unsigned piece = ((lane & 7) ^ ((srow >> 1) & 7)) << 4;
     const unsigned lane_off_w = static_cast<unsigned>(srow * w_pitch) + piece, lane_off_x = static_cast<unsigned>(srow * x_pitch) + piece;
-    const int dbg = p.flags;
-    auto stage = [&](int buf, int t, int kt) {
-        const int mt = t / tiles_n, nt = t - mt * tiles_n;
-        const unsigned char *wbase = wb + static_cast<int64_t>(nt) * BN * w_pitch + kt * (kLinBK * 2);
-        const unsigned char *xbase = xb + static_cast<int64_t>(mt) * BM * x_pitch + kt * (kLinBK * 2);
+    int is_tile = tile0, is_kt = 0, is_g = 0;                      // issue cursor: next (tile, k-step) to fetch, stage is_g % NST
+    auto issue = [&]() {
+        const int mt = is_tile / tiles_n, nt = is_tile - mt * tiles_n;
+        const unsigned char *wbase = wb + static_cast<int64_t>(nt) * BN * w_pitch + is_kt * (kLinBK * 2);
+        const unsigned char *xbase = xb + static_cast<int64_t>(mt) * BM * x_pitch + is_kt * (kLinBK * 2);
         const int64_t rows_left = p.m - static_cast<int64_t>(mt) * BM;      // m % 8 == 0: a group of 8 rows exists or does not
+        unsigned char *dst = smem + (is_g % NST) * STAGE;
 #pragma unroll
         for (int i = 0; i < NLD; ++i) {
             const unsigned char *src;
@@ -145,37 +172,41 @@ __global__ __launch_bounds__(512, 2) void linear_tn_kernel(const zigma_linear_pa
                 const int r0 = (i - BN / 64) * 64;
                 src = xbase + (r0 + wave * 8 < rows_left ? static_cast<int64_t>(r0) * x_pitch : -static_cast<int64_t>(wave * 8) * x_pitch) + lane_off_x;
             }
-            __builtin_amdgcn_global_load_lds((gbl_ptr_t)(src), (lds_ptr_t)(smem) + buf * STAGE + (i * 8 + wave) * 1024, 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gbl_ptr_t)(src), (lds_ptr_t)(dst) + (i * 8 + wave) * 1024, 16, 0, 0);
         }
+        ++is_g;
+        if (++is_kt == nk) { is_kt = 0; is_tile += wg_per_xcd; }
     };
 
     // fragment read offsets: row * 128 + (((ks << 1) | kh) ^ ((row >> 1) & 7)) * 16, row = base (multiple of 32) + j
     const int sw = (j >> 1) & 7;
     const int a_row0 = (wn * 64 + j) * 128, b_row0 = (BN + wm * (BM / WM_) + j) * 128;
 
-    if (HAS_BIAS) {                                                // before the first direct-to-LDS load; visible to all after the first barrier
+    if (HAS_BIAS) {                                                // plain loads + LDS writes, retired before the pipeline starts counting
         for (int i = tid; i < p.n / 2; i += 512)
-            reinterpret_cast<uint32_t *>(smem + 2 * STAGE)[i] = reinterpret_cast<const uint32_t *>(p.bias)[i];
+            reinterpret_cast<uint32_t *>(smem + NST * STAGE)[i] = reinterpret_cast<const uint32_t *>(p.bias)[i];
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
-    int buf = 0;
-    stage(0, tile, 0);
 #pragma unroll 1
-    while (true) {
-        const int next = tile + wg_per_xcd;
-        const bool has_next = next < chunk_end;
+    for (int g0 = 0; g0 < NST - 1 && g0 < g_total; ++g0) issue();
+
+    int g = 0, tile = tile0;
+#pragma unroll 1
+    for (int ti = 0; ti < my_tiles; ++ti, tile += wg_per_xcd) {
         f32x16 acc[NB][MB];
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
             for (int mb = 0; mb < MB; ++mb) acc[nb][mb] = f32x16{};
 #pragma unroll 1
-        for (int kt = 0; kt < nk; ++kt) {
-            __syncthreads();                // stage `buf` has landed (vmcnt(0) before the barrier); stage buf^1 is free again
-            if (!(dbg & 0x200)) {
-                if (kt + 1 < nk) stage(buf ^ 1, tile, kt + 1);
-                else if (has_next) stage(buf ^ 1, next, 0);
-            }
-            const unsigned char *sb = smem + buf * STAGE;
+        for (int kt = 0; kt < nk; ++kt, ++g) {
+            // batch g has landed when only what was issued after it is still outstanding: the younger batches (NST - 2 of
+            // them, fewer at the very end) and, right after an epilogue, its stores
+            const int younger = (g_total - 1 - g) < (NST - 2) ? (g_total - 1 - g) : (NST - 2);
+            wait_vm(NLD * younger + ((ti > 0 && kt < NST - 1 && !(dbg & 0x400)) ? NSTORE : 0));
+            __builtin_amdgcn_s_barrier();                       // ... for every wave; and every wave is done with stage (g - 1) % NST
+            if (g + NST - 1 < g_total && !(dbg & 0x200)) issue();
+            const unsigned char *sb = smem + (g % NST) * STAGE;
             // fragments one k-substep ahead of the MFMAs that use them (the LDS latency hides under the previous 8 MFMAs)
             bf16x8 a[2][NB], b[2][MB];
             auto frags = [&](int ks, bf16x8 (&fa)[NB], bf16x8 (&fb)[MB]) {
@@ -187,7 +218,7 @@ __global__ __launch_bounds__(512, 2) void linear_tn_kernel(const zigma_linear_pa
                 for (int mb = 0; mb < MB; ++mb)
                     fb[mb] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4 *>(sb + b_row0 + mb * 32 * 128 + off));
             };
-            if (dbg & 0x100) { buf ^= 1; continue; }
+            if (dbg & 0x100) continue;
             frags(0, a[0], b[0]);
 #pragma unroll
             for (int ks = 0; ks < kLinBK / 16; ++ks) {
@@ -205,19 +236,20 @@ __global__ __launch_bounds__(512, 2) void linear_tn_kernel(const zigma_linear_pa
 #pragma unroll
                 for (int ks = 0; ks + 1 < kLinBK / 16; ++ks) {
 #pragma unroll
-                    for (int r = 0; r < NB + MB; ++r) {
+                    for (int r = 0; r < (NB + MB < NB * MB ? NB + MB : NB * MB); ++r) {
                         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
                         __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
                     }
-                    __builtin_amdgcn_sched_group_barrier(0x008, NB * MB - (NB + MB), 0);
+                    if (NB * MB > NB + MB) __builtin_amdgcn_sched_group_barrier(0x008, NB * MB - (NB + MB), 0);
                 }
                 __builtin_amdgcn_sched_group_barrier(0x008, NB * MB, 0);
             }
-            buf ^= 1;
         }
-        // ---- epilogue: transposed through the stage the main loop has just finished with ----------------------------------------
+        // ---- epilogue: transposed through the stage the main loop has just finished with (the next issue into it happens
+        // behind the next k-step's barrier) ---------------------------------------------------------------------------------
         if (!(dbg & 0x400)) {
-            __syncthreads();                                                                  // every wave is done with the fragments of this stage
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();                                                     // every wave is done with the fragments of this stage
             const int mt = tile / tiles_n, nt = tile - mt * tiles_n;
             const int64_t m_tile = static_cast<int64_t>(mt) * BM + wm * (BM / WM_);           // first token of this wave's tile
             const int64_t rows_here = p.m - m_tile;                                            // tokens of it that exist
@@ -226,261 +258,9 @@ __global__ __launch_bounds__(512, 2) void linear_tn_kernel(const zigma_linear_pa
             // tokens beyond m fall outside the extent and are dropped by the hardware
             const rsrc_t o_rs = make_rsrc(reinterpret_cast<unsigned char *>(p.out) + m_tile * o_pitch + (nt * BN + wn * 64) * 2,
                                           rows_here > 0 ? (rows_here < BM / WM_ ? rows_here : BM / WM_) * o_pitch - (nt * BN + wn * 64) * 2 : 0);
-            linear_epilogue<MB, NB>(acc, smem + (buf ^ 1) * STAGE + wave * 4096,
-                                    HAS_BIAS ? reinterpret_cast<const uint16_t *>(smem + 2 * STAGE) : nullptr, o_rs, o_pitch, nt * BN + wn * 64,
-                                    p.silu_from_col, lane);                                   // (buf already points at the next stage)
-        }
-        if (!has_next) break;
-        tile = next;
-    }
-}
-
-
-// ---------------------------------------------------------------------------------------------------------------------------
-// Third arrangement: TWO workgroups per CU.  128 tokens x 256 features per workgroup, 4 waves (one per SIMD, wave tile 64 x 128 as
-// in the 256 x 256 kernel), BK = 32, two 24 KB stages -> 48 KB of LDS and <= 256 VGPRs per wave, so two workgroups share a CU.
-// The first pipeline's loss is structural: one workgroup per CU means every wave of the CU waits at the same barrier, loads
-// are exposed whenever they take longer than one k-step, and nothing runs during the epilogue's stores.  Two independent
-// workgroups per CU interleave on their own (the CU's other workgroup issues MFMAs while this one waits or stores), at the
-// price of 1.5 x the L2 -> LDS traffic per flop (128 x 256 instead of 256 x 256 tiles).
-template <bool HAS_BIAS>
-__global__ __launch_bounds__(256, 2) void linear_tn3_kernel(const zigma_linear_params_t p, const int tiles_m, const int tiles_n) {
-    constexpr int BM = 128, BN = 256, BK = 32, MB = 4, NB = 2;
-    constexpr int ROWS = BN + BM, STAGE = ROWS * BK * 2;         // 24 KB per stage: W rows first, then token rows (64 B each)
-    constexpr int NLD = STAGE / 1024 / 4;                          // 6 direct-to-LDS loads per wave per stage (16 rows x 64 B each)
-    __shared__ __attribute__((aligned(1024))) unsigned char smem[2 * STAGE + (HAS_BIAS ? 32768 : 0)];
-
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // = n position of the wave tile (4 x 64 features)
-    const int j = lane & 31, kh = lane >> 5;
-    const int nk = p.k / BK;
-    const unsigned char *xb = reinterpret_cast<const unsigned char *>(p.x);
-    const unsigned char *wb = reinterpret_cast<const unsigned char *>(p.w);
-    const int64_t x_pitch = p.x_row_stride * 2, w_pitch = p.w_row_stride * 2;
-
-    const int n_tiles = tiles_m * tiles_n;
-    const int xcd = blockIdx.x & 7, slot_in_xcd = blockIdx.x >> 3, wg_per_xcd = gridDim.x >> 3;
-    const int chunk = (n_tiles + 7) >> 3;
-    const int chunk_end = (xcd + 1) * chunk < n_tiles ? (xcd + 1) * chunk : n_tiles;
-    int tile = xcd * chunk + slot_in_xcd;
-    if (tile >= chunk_end) return;
-
-    // staging: instruction i of wave w fills rows q*16 .. q*16+15 of a stage, q = i * 4 + w (W rows first: i < 4);
-    // lane -> row (lane >> 2), 16-byte slot (lane & 3) holding source piece (lane & 3) ^ ((row >> 2) & 3)
-    const int srow = wave * 16 + (lane >> 2);
-    const unsigned piece = ((lane & 3) ^ ((lane >> 4) & 3)) << 4;
-    const unsigned lane_off_w = static_cast<unsigned>(srow * w_pitch) + piece, lane_off_x = static_cast<unsigned>(srow * x_pitch) + piece;
-    auto stage = [&](int buf, int t, int kt) {
-        const int mt = t / tiles_n, nt = t - mt * tiles_n;
-        const unsigned char *wbase = wb + static_cast<int64_t>(nt) * BN * w_pitch + kt * (BK * 2);
-        const unsigned char *xbase = xb + static_cast<int64_t>(mt) * BM * x_pitch + kt * (BK * 2);
-        const int64_t rows_left = p.m - static_cast<int64_t>(mt) * BM;      // m % 16 == 0: a group of 16 rows exists or does not
-#pragma unroll
-        for (int i = 0; i < NLD; ++i) {
-            const unsigned char *src;
-            if (i < BN / 64) {
-                src = wbase + static_cast<int64_t>(i * 64) * w_pitch + lane_off_w;
-            } else {
-                const int r0 = (i - BN / 64) * 64;
-                src = xbase + (r0 + wave * 16 < rows_left ? static_cast<int64_t>(r0) * x_pitch : -static_cast<int64_t>(wave * 16) * x_pitch) + lane_off_x;
-            }
-            __builtin_amdgcn_global_load_lds((gbl_ptr_t)(src), (lds_ptr_t)(smem) + buf * STAGE + (i * 4 + wave) * 1024, 16, 0, 0);
-        }
-    };
-    // fragment reads: row * 64 + ((ksub * 2 + kh) ^ ((row >> 2) & 3)) * 16, row = base (multiple of 32) + j
-    const int sw = (j >> 2) & 3;
-    const int a_row0 = (wave * 64 + j) * 64, b_row0 = (BN + j) * 64;
-    const int off0 = ((kh ^ sw) << 4), off1 = (((2 | kh) ^ sw) << 4);
-
-    if (HAS_BIAS) {
-        for (int i = tid; i < p.n / 2; i += 256)
-            reinterpret_cast<uint32_t *>(smem + 2 * STAGE)[i] = reinterpret_cast<const uint32_t *>(p.bias)[i];
-    }
-    int buf = 0;
-    stage(0, tile, 0);
-#pragma unroll 1
-    while (true) {
-        const int next = tile + wg_per_xcd;
-        const bool has_next = next < chunk_end;
-        f32x16 acc[NB][MB];
-#pragma unroll
-        for (int nb = 0; nb < NB; ++nb)
-#pragma unroll
-            for (int mb = 0; mb < MB; ++mb) acc[nb][mb] = f32x16{};
-#pragma unroll 1
-        for (int kt = 0; kt < nk; ++kt) {
-            __syncthreads();
-            if (kt + 1 < nk) stage(buf ^ 1, tile, kt + 1);
-            else if (has_next) stage(buf ^ 1, next, 0);
-            const unsigned char *sb = smem + buf * STAGE;
-            bf16x8 a[2][NB], b[2][MB];
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
-                const int off = ks ? off1 : off0;
-#pragma unroll
-                for (int nb = 0; nb < NB; ++nb)
-                    a[ks][nb] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4 *>(sb + a_row0 + nb * 32 * 64 + off));
-#pragma unroll
-                for (int mb = 0; mb < MB; ++mb)
-                    b[ks][mb] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4 *>(sb + b_row0 + mb * 32 * 64 + off));
-            }
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-                for (int nb = 0; nb < NB; ++nb)
-#pragma unroll
-                    for (int mb = 0; mb < MB; ++mb)
-                        acc[nb][mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ks][nb], b[ks][mb], acc[nb][mb], 0, 0, 0);
-            __builtin_amdgcn_sched_group_barrier(0x100, NB + MB, 0);       // reads of sub-step 1 between the MFMAs of sub-step 0
-#pragma unroll
-            for (int r = 0; r < NB + MB; ++r) {
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-            }
-            __builtin_amdgcn_sched_group_barrier(0x008, 2 * NB * MB - (NB + MB), 0);
-            buf ^= 1;
-        }
-        if (!(p.flags & 0x400)) {
-            __syncthreads();                                                                  // every wave is done with the fragments of this stage
-            const int mt = tile / tiles_n, nt = tile - mt * tiles_n;
-            const int64_t m_tile = static_cast<int64_t>(mt) * BM;
-            const int64_t rows_here = p.m - m_tile;
-            const int64_t o_pitch = p.out_row_stride * 2;
-            const rsrc_t o_rs = make_rsrc(reinterpret_cast<unsigned char *>(p.out) + m_tile * o_pitch + (nt * BN + wave * 64) * 2,
-                                          rows_here > 0 ? (rows_here < BM ? rows_here : BM) * o_pitch - (nt * BN + wave * 64) * 2 : 0);
-            linear_epilogue<MB, NB>(acc, smem + (buf ^ 1) * STAGE + wave * 4096,
-                                    HAS_BIAS ? reinterpret_cast<const uint16_t *>(smem + 2 * STAGE) : nullptr, o_rs, o_pitch, nt * BN + wave * 64,
+            linear_epilogue<MB, NB>(acc, smem + ((g - 1) % NST) * STAGE + wave * 4096,
+                                    HAS_BIAS ? reinterpret_cast<const uint16_t *>(smem + NST * STAGE) : nullptr, o_rs, o_pitch, nt * BN + wn * 64,
                                     p.silu_from_col, lane);
-        }
-        if (!has_next) break;
-        tile = next;
-    }
-}
-
-// ---------------------------------------------------------------------------------------------------------------------------
-// Second pipeline: the same tiles, fragments and epilogue, but the k-loop runs in HALF steps of 32 columns through a ring of
-// four 32-column LDS slots, with loads issued three half-steps (1.5 k-steps) ahead and a COUNTED s_waitcnt vmcnt (never 0 in
-// steady state) in front of a raw s_barrier: measured on the first pipeline, one k-step of MFMAs (~1.5 us at the clock this
-// kernel sustains) does not cover the latency of the loads issued one k-step ahead (~1 us for 64 KB per CU with every CU
-// asking at once), and __syncthreads() drains the direct-to-LDS queue at every step.  The epilogue transposes through a
-// dedicated 32 KB scratch area (no barrier: wave-private), so the ring keeps running across tile boundaries; its stores share
-// the vmcnt counter with the loads, which only makes the counted waits conservative (loads return in order among loads).
-template <int WN_, bool HAS_BIAS>
-__global__ __launch_bounds__(512, 2) void linear_tn2_kernel(const zigma_linear_params_t p, const int tiles_m, const int tiles_n) {
-    constexpr int BM = kLinBM, BN = 64 * WN_, WM_ = 8 / WN_, MB = BM / WM_ / 32, NB = 2;
-    constexpr int ROWS = BN + BM, HSLOT = ROWS * 64;             // bytes per ring slot: ROWS rows x 32 bf16
-    constexpr int NLDH = ROWS / 128;                               // direct-to-LDS loads per wave per slot (16 rows x 64 B each)
-    constexpr int SCR = 4 * HSLOT;
-    static_assert(!HAS_BIAS || WN_ == 2, "the bias vector is staged in the LDS the 256 x 128 tile leaves free");
-    // ONE LDS object (a second one makes hipcc drain vmcnt in front of every fragment read, cdna_hip_programming.md §5):
-    // [4 ring slots][8 x 4 KB epilogue scratch][bias, bf16, n <= 16384]
-    __shared__ __attribute__((aligned(1024))) unsigned char smem[4 * HSLOT + 8 * 4096 + (HAS_BIAS ? 32768 : 0)];
-
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wn = wave % WN_, wm = wave / WN_;
-    const int j = lane & 31, kh = lane >> 5;
-    const int nk = p.k / kLinBK;
-    const unsigned char *xb = reinterpret_cast<const unsigned char *>(p.x);
-    const unsigned char *wb = reinterpret_cast<const unsigned char *>(p.w);
-    const int64_t x_pitch = p.x_row_stride * 2, w_pitch = p.w_row_stride * 2;
-
-    const int n_tiles = tiles_m * tiles_n;
-    const int xcd = blockIdx.x & 7, slot_in_xcd = blockIdx.x >> 3, wg_per_xcd = gridDim.x >> 3;
-    const int chunk = (n_tiles + 7) >> 3;
-    const int chunk_end = (xcd + 1) * chunk < n_tiles ? (xcd + 1) * chunk : n_tiles;
-    const int tile0 = xcd * chunk + slot_in_xcd;
-    if (tile0 >= chunk_end) return;
-    const int my_tiles = (chunk_end - tile0 + wg_per_xcd - 1) / wg_per_xcd;
-    const int h_total = my_tiles * nk * 2;                         // half-steps of this workgroup's whole run
-
-    // staging: instruction i of wave w fills rows q*16 .. q*16+15 of a slot, q = i * 8 + w (W rows first: i < BN / 128);
-    // lane -> row (lane >> 2), 16-byte slot (lane & 3) holding source piece (lane & 3) ^ ((row >> 2) & 3)
-    const int srow = wave * 16 + (lane >> 2);
-    const unsigned piece = ((lane & 3) ^ ((lane >> 4) & 3)) << 4;
-    const unsigned lane_off_w = static_cast<unsigned>(srow * w_pitch) + piece, lane_off_x = static_cast<unsigned>(srow * x_pitch) + piece;
-    int is_tile = tile0, is_kt = 0, is_half = 0, is_h = 0;         // issue cursor
-    auto issue = [&]() {
-        const int mt = is_tile / tiles_n, nt = is_tile - mt * tiles_n;
-        const int koff = is_kt * (kLinBK * 2) + is_half * 64;
-        const unsigned char *wbase = wb + static_cast<int64_t>(nt) * BN * w_pitch + koff;
-        const unsigned char *xbase = xb + static_cast<int64_t>(mt) * BM * x_pitch + koff;
-        const int64_t rows_left = p.m - static_cast<int64_t>(mt) * BM;  // m % 16 == 0: a group of 16 rows exists or does not
-        unsigned char *dst = smem + (is_h & 3) * HSLOT;
-#pragma unroll
-        for (int i = 0; i < NLDH; ++i) {
-            const unsigned char *src;
-            if (i < BN / 128) {
-                src = wbase + static_cast<int64_t>(i * 128) * w_pitch + lane_off_w;
-            } else {
-                const int r0 = (i - BN / 128) * 128;
-                src = xbase + (r0 + wave * 16 < rows_left ? static_cast<int64_t>(r0) * x_pitch : -static_cast<int64_t>(wave * 16) * x_pitch) + lane_off_x;
-            }
-            __builtin_amdgcn_global_load_lds((gbl_ptr_t)(src), (lds_ptr_t)(dst) + (i * 8 + wave) * 1024, 16, 0, 0);
-        }
-        ++is_h;
-        if (++is_half == 2) { is_half = 0; if (++is_kt == nk) { is_kt = 0; is_tile += wg_per_xcd; } }
-    };
-
-    // fragment reads: row * 64 + ((ksub * 2 + kh) ^ ((row >> 2) & 3)) * 16, row = base (multiple of 32) + j
-    const int sw = (j >> 2) & 3;
-    const int a_row0 = (wn * 64 + j) * 64, b_row0 = (BN + wm * (BM / WM_) + j) * 64;
-    const int off0 = ((kh ^ sw) << 4), off1 = (((2 | kh) ^ sw) << 4);
-
-    if (HAS_BIAS) {                                                // visible to every wave after the first barrier of the ring
-        for (int i = tid; i < p.n / 2; i += 512)
-            reinterpret_cast<uint32_t *>(smem + SCR + 8 * 4096)[i] = reinterpret_cast<const uint32_t *>(p.bias)[i];
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // (plain loads: off the counter before the ring starts counting)
-    }
-#pragma unroll 1
-    for (int h = 0; h < 3 && h < h_total; ++h) issue();
-
-    int g = 0;
-    int tile = tile0;
-#pragma unroll 1
-    for (int ti = 0; ti < my_tiles; ++ti, tile += wg_per_xcd) {
-        f32x16 acc[NB][MB];
-#pragma unroll
-        for (int nb = 0; nb < NB; ++nb)
-#pragma unroll
-            for (int mb = 0; mb < MB; ++mb) acc[nb][mb] = f32x16{};
-#pragma unroll 1
-        for (int hs = 0; hs < 2 * nk; ++hs, ++g) {
-            // the slot of half-step g has landed when at most the two younger batches are still in flight
-            const int rem = h_total - 1 - g;
-            if (rem >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NLDH) : "memory");
-            else if (rem == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NLDH) : "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();                       // ... for every wave; and every wave is done reading slot g - 1
-            if (g + 3 < h_total) issue();                        // refill slot (g + 3) & 3 == (g - 1) & 3
-            const unsigned char *sb = smem + (g & 3) * HSLOT;
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
-                const int off = ks ? off1 : off0;
-                bf16x8 a[NB], b[MB];
-#pragma unroll
-                for (int nb = 0; nb < NB; ++nb)
-                    a[nb] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4 *>(sb + a_row0 + nb * 32 * 64 + off));
-#pragma unroll
-                for (int mb = 0; mb < MB; ++mb)
-                    b[mb] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4 *>(sb + b_row0 + mb * 32 * 64 + off));
-#pragma unroll
-                for (int nb = 0; nb < NB; ++nb)
-#pragma unroll
-                    for (int mb = 0; mb < MB; ++mb)
-                        acc[nb][mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[nb], b[mb], acc[nb][mb], 0, 0, 0);
-            }
-        }
-        // ---- epilogue: scratch is a dedicated wave-private 4 KB, so no barrier and the ring keeps running ---------------------
-        if (!(p.flags & 0x400)) {
-            const int mt = tile / tiles_n, nt = tile - mt * tiles_n;
-            const int64_t m_tile = static_cast<int64_t>(mt) * BM + wm * (BM / WM_);
-            const int64_t rows_here = p.m - m_tile;
-            const int64_t o_pitch = p.out_row_stride * 2;
-            const rsrc_t o_rs = make_rsrc(reinterpret_cast<unsigned char *>(p.out) + m_tile * o_pitch + (nt * BN + wn * 64) * 2,
-                                          rows_here > 0 ? (rows_here < BM / WM_ ? rows_here : BM / WM_) * o_pitch - (nt * BN + wn * 64) * 2 : 0);
-            linear_epilogue<MB, NB>(acc, smem + SCR + wave * 4096, HAS_BIAS ? reinterpret_cast<const uint16_t *>(smem + SCR + 8 * 4096) : nullptr,
-                                    o_rs, o_pitch, nt * BN + wn * 64, p.silu_from_col, lane);
         }
     }
 }
@@ -494,7 +274,7 @@ extern "C" int zigma_linear_fwd(const zigma_linear_params_t *pp, void *stream_) 
     (void)hipGetLastError();
     const zigma_linear_params_t &p = *pp;
     if (p.m < 0 || p.n < 1 || p.k < 1) return ZIGMA_ERR_SHAPE;
-    if (p.flags & ~0x7f00) return ZIGMA_ERR_UNSUPPORTED;     // 0x100 ... 0x1000: timing / A-B probes (tools/linear_probe.py)
+    if (p.flags & ~0x1f00) return ZIGMA_ERR_UNSUPPORTED;     // 0x100 ... 0x1000: timing / A-B probes (tools/linear_probe.py)
     if (p.m == 0) return ZIGMA_OK;
     if (!p.x || !p.w || !p.out) return ZIGMA_ERR_NULL;
     if (p.dtype != ZIGMA_BF16) return ZIGMA_ERR_DTYPE;
@@ -508,41 +288,18 @@ extern "C" int zigma_linear_fwd(const zigma_linear_params_t *pp, void *stream_) 
         return ZIGMA_ERR_STRIDE;
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     const int tiles_m = static_cast<int>((p.m + kLinBM - 1) / kLinBM);
-    // 0x1000: force the 256 x 128 tile (probe).
-    const bool ring = (p.flags & 0x800) && p.m % 16 == 0;         // 0x800: the half-step ring pipeline (measured slower: A/B probe only)
-    const bool wide = p.n % 256 == 0 && !(p.flags & 0x1000) && !(ring && p.bias);
-    if (p.bias && (p.n > 16384 || reinterpret_cast<uintptr_t>(p.bias) % 4 != 0)) return ZIGMA_ERR_SHAPE;
+    const bool wide = p.n % 256 == 0 && !(p.flags & 0x1000);      // 0x1000: force the 256 x 128 tile (probe)
+    if (p.bias && (p.n > 4096 || reinterpret_cast<uintptr_t>(p.bias) % 4 != 0)) return ZIGMA_ERR_SHAPE;
     const int tiles_n = p.n / (wide ? 256 : 128);
     const int64_t n_tiles = static_cast<int64_t>(tiles_m) * tiles_n;
     if (n_tiles > 0x7fffffff) return ZIGMA_ERR_SHAPE;
     int grid = 256;                                  // one persistent workgroup per CU; multiples of 8 keep the XCD map
     if (n_tiles < grid) grid = static_cast<int>((n_tiles + 7) / 8 * 8);
-    if ((p.flags & 0x2000) && p.n % 256 == 0 && p.m % 16 == 0) {        // 0x2000: two workgroups per CU, 128 x 256 tiles
-        const int tm = static_cast<int>((p.m + 127) / 128), tn = p.n / 256;
-        const int64_t nt3 = static_cast<int64_t>(tm) * tn;
-        if (nt3 > 0x7fffffff) return ZIGMA_ERR_SHAPE;
-        int g3 = 512;
-        if (nt3 < g3) g3 = static_cast<int>((nt3 + 7) / 8 * 8);
-        if (p.bias) hipLaunchKernelGGL((linear_tn3_kernel<true>), dim3(g3), dim3(256), 0, stream, p, tm, tn);
-        else hipLaunchKernelGGL((linear_tn3_kernel<false>), dim3(g3), dim3(256), 0, stream, p, tm, tn);
-        set_last_kernel("linear_tn3_128x256");
-        return check_launch();
-    }
-    if (ring) {
-        if (wide) hipLaunchKernelGGL((linear_tn2_kernel<4, false>), dim3(grid), dim3(512), 0, stream, p, tiles_m, tiles_n);
-        else if (p.bias) hipLaunchKernelGGL((linear_tn2_kernel<2, true>), dim3(grid), dim3(512), 0, stream, p, tiles_m, tiles_n);
-        else hipLaunchKernelGGL((linear_tn2_kernel<2, false>), dim3(grid), dim3(512), 0, stream, p, tiles_m, tiles_n);
-        set_last_kernel(wide ? "linear_tn2_256x256" : "linear_tn2_256x128");
-        return check_launch();
-    }
-
-    if (wide) {
-        if (p.bias) hipLaunchKernelGGL((linear_tn_kernel<4, true>), dim3(grid), dim3(512), 0, stream, p, tiles_m, tiles_n);
-        else hipLaunchKernelGGL((linear_tn_kernel<4, false>), dim3(grid), dim3(512), 0, stream, p, tiles_m, tiles_n);
-    } else {
-        if (p.bias) hipLaunchKernelGGL((linear_tn_kernel<2, true>), dim3(grid), dim3(512), 0, stream, p, tiles_m, tiles_n);
-        else hipLaunchKernelGGL((linear_tn_kernel<2, false>), dim3(grid), dim3(512), 0, stream, p, tiles_m, tiles_n);
-    }
+#define ZIGMA_LIN(W_, S_, B_) hipLaunchKernelGGL((linear_tn_kernel<W_, S_, B_>), dim3(grid), dim3(512), 0, stream, p, tiles_m, tiles_n)
+    if (wide) { if (p.bias) ZIGMA_LIN(4, 2, true); else ZIGMA_LIN(4, 2, false); }
+    else if (p.flags & 0x800) { if (p.bias) ZIGMA_LIN(2, 2, true); else ZIGMA_LIN(2, 2, false); }      // 0x800: two stages (probe)
+    else { if (p.bias) ZIGMA_LIN(2, 3, true); else ZIGMA_LIN(2, 3, false); }
+#undef ZIGMA_LIN
     set_last_kernel(wide ? "linear_tn_256x256" : "linear_tn_256x128");
     return check_launch();
 }

@@ -191,6 +191,33 @@ extern "C" int zigma_selective_scan_fwd(const zigma_scan_params_t *pp, void *str
     if (p.reset_period < 0 || p.reset_period % 16 != 0 || (p.reset_period > 0 && p.x)) return ZIGMA_ERR_SHAPE;
     if (p.reset_period > 0 && !tok_eligible(p)) return ZIGMA_ERR_STRIDE;   // only the token-major kernel restarts sequences
     if ((p.flags & ZIGMA_SCAN_Z_PREACTIVATED) && !(tok_eligible(p) && p.io_dtype != ZIGMA_F32)) return ZIGMA_ERR_UNSUPPORTED;
+    if (tok_eligible(p) && p.batch > 65535) {
+        // the first-generation token-major kernel carries the batch in gridDim.y: larger batches (video temporal layers:
+        // batch x tokens-per-frame rows) run in slices.  checkpoints are per (batch, slab): sliced alike.
+        const size_t es = p.io_dtype == ZIGMA_F32 ? 4 : 2;
+        const int chunk_len = p.chunk_len > 0 ? p.chunk_len : 2048;
+        const int64_t n_chunks = (p.seqlen + chunk_len - 1) / chunk_len, n_tiles = (p.seqlen + 15) / 16;
+        for (int b0 = 0; b0 < p.batch; b0 += 65535) {
+            zigma_scan_params_t q = p;
+            q.batch = p.batch - b0 < 65535 ? p.batch - b0 : 65535;
+            auto adv = [&](const void *ptr, int64_t stride_elems, size_t esz) -> const void * {
+                return ptr ? reinterpret_cast<const char *>(ptr) + static_cast<int64_t>(b0) * stride_elems * static_cast<int64_t>(esz) : nullptr;
+            };
+            q.u = adv(p.u, p.u_batch_stride, es);
+            q.delta = adv(p.delta, p.delta_batch_stride, es);
+            q.z = adv(p.z, p.z_batch_stride, es);
+            q.out = const_cast<void *>(adv(p.out, p.out_batch_stride, es));
+            q.out_z = const_cast<void *>(adv(p.out_z, p.out_z_batch_stride, es));
+            q.B = adv(p.B, p.B_batch_stride, es);
+            q.C = adv(p.C, p.C_batch_stride, es);
+            q.x = const_cast<void *>(adv(p.x, static_cast<int64_t>(p.dim) * n_chunks * 2 * p.dstate, 4));
+            q.checkpoints = reinterpret_cast<float *>(const_cast<void *>(
+                adv(p.checkpoints, static_cast<int64_t>(p.dim / 64) * n_tiles * p.dstate * 64, 4)));
+            const int rc = zigma_selective_scan_fwd(&q, stream_);
+            if (rc != ZIGMA_OK) return rc;
+        }
+        return ZIGMA_OK;
+    }
     if (tok_eligible(p)) {
         switch (p.io_dtype) {
             case ZIGMA_BF16: return launch_scan_tok_bf16(p, stream);
