@@ -311,11 +311,16 @@ def main():
             # instruction per SIMD, transcendental quarter rate = 8): 4 plain + 1 exp per (element, state), 1024 SIMDs
             groups = batch * L * Di * N / 64
             valu_floor_us = groups * (4 * 2 + 8) / (1024 * SCLK) * 1e6
+            # the same floor at the rates this chip sustains (tools/ubench2, profiles/r02_ubench2_valu_rates.txt: wall ns per
+            # wave instruction per SIMD — v_exp_f32 3.43, v_pk_mul/fma_f32 2.28 for two results, plain VOP2 1.35): per 4 states
+            # 4 exp + 6 packed + 4 plain = 32.8 ns
+            valu_floor_measured_us = groups / 4 * (4 * 3.43 + 6 * 2.28 + 4 * 1.35) * 1e-9 / 1024 * 1e6
             roof = dict(bound="hbm", kernel="scan_tok (fused zigzag selective scan)", achieved=ach / 1e9,
                         peak=HBM_PEAK / 1e9, unit="GB/s", frac=ach / HBM_PEAK, traffic=traffic,
                         traffic_source=traffic_src, launch_us=ms * 1e3, launches=len(timer.pairs),
                         algorithmic_bytes=algo_bytes, limiter="valu", valu_floor_us=valu_floor_us,
-                        valu_frac=valu_floor_us / (ms * 1e3))
+                        valu_frac=valu_floor_us / (ms * 1e3), valu_floor_measured_rates_us=valu_floor_measured_us,
+                        valu_frac_measured_rates=valu_floor_measured_us / (ms * 1e3))
         line = dict(metric="denoiser-forward latents/sec (BxL tokens/s), ZigMa d=640 L=32^2",
                     value=world * batch * L * args.steps / elapsed, unit="tokens/s", n_gpus=world, steps=args.steps,
                     warmup=args.warmup, ms_per_step=elapsed / args.steps * 1e3, higher_is_better=True, scaling="weak",
