@@ -380,6 +380,32 @@ typedef struct zigma_xproj_params {
 int zigma_x_proj_fwd(const zigma_xproj_params_t *p, void *stream);
 
 /* ------------------------------------------------------------------------------------------
+ * conv_x_proj: the depthwise causal conv1d (+ bias, SiLU) over the reordered sequence AND x_proj of its result in one pass:
+ *   u[b, k, c]   = silu(conv_bias[c] + sum_{w<4} conv_weight[c, w] * x[b, x_row_index[k - 3 + w], c])     (x[<0] = 0)
+ *   out[b*L + k, n] = sum_c u[b, k, c] * w[n, c]
+ * Replaces causal_conv1d_fn(..., activation="silu") + F.linear(conv1d_out, x_proj_weight) of MambaInnerFn.forward
+ * (reference selective_scan_interface.py:307-322) with the gather of mamba_simple.py:362-370 in the loads.  u (needed by
+ * the scan) is written once and not read back.  bf16 throughout, fp32 accumulation; u is rounded to bf16 BEFORE the
+ * projection, as in the reference.  x: (batch, seqlen, dim) channel-contiguous rows; conv_weight: (dim, 4) contiguous;
+ * conv_bias: (dim); w: (n, dim) rows; u: (batch, seqlen, dim) in scan order; out: (batch * seqlen, n) rows.
+ * Limits: width 4, bias required, seqlen % 32 == 0, batch * seqlen % 256 == 0, dim % 64 == 0, n <= 96, 16-byte aligned rows.
+ * flags: bit 0 = two LDS stages instead of three (probe).
+ * ------------------------------------------------------------------------------------------ */
+typedef struct zigma_conv_xproj_params {
+    int32_t batch, seqlen, dim, n;
+    int32_t dtype;           /* ZIGMA_BF16 */
+    int32_t flags;
+    int64_t x_batch_stride, x_l_stride;
+    int64_t u_batch_stride, u_l_stride;
+    int64_t w_row_stride, out_row_stride;
+    const void *x, *conv_weight, *conv_bias, *w;
+    void *u, *out;
+    const int32_t *x_row_index;   /* or NULL */
+} zigma_conv_xproj_params_t;
+
+int zigma_conv_x_proj_fwd(const zigma_conv_xproj_params_t *p, void *stream);
+
+/* ------------------------------------------------------------------------------------------
  * Dense projection on the matrix cores:  out = x @ w^T (+ bias) (+ SiLU on a column range), bf16 in / fp32 accumulate / bf16 out.
  * Replaces the cuBLAS GEMMs behind F.linear at Mamba.in_proj (reference mamba_simple.py:290-294), out_proj
  * (selective_scan_interface.py:365) and CrossAttention.to_q / to_out (model_zigma.py:104-135).

@@ -500,6 +500,45 @@ def test_x_proj_kernel_vs_oracle(M, K, Nn):
     assert rel_err(N(out), ref) < 3e-3 and np.allclose(N(out), ref, rtol=2e-2, atol=2e-2)
 
 
+@pytest.mark.parametrize("Bsz,L,Di,Nn,order,two_stage", [(2, 128, 64, 72, "id", False), (1, 256, 192, 40, "rand", False),
+                                                       (16, 1024, 1280, 72, "rand", False), (64, 256, 128, 96, "none", False),
+                                                       (4, 4096, 640, 72, "rev", True)])
+def test_conv_x_proj_kernel_vs_oracle(Bsz, L, Di, Nn, order, two_stage):
+    """The one-pass conv + SiLU + x_proj kernel vs float64 numpy on the same bf16 operands: u (bf16-rounded conv output in scan
+    order) and x_dbl = u @ W_x^T evaluated on the kernel's OWN u (the reference rounds u to bf16 before the projection too);
+    and against the two separate kernels (same u up to single bf16 roundings of an fp32 sum associated differently)."""
+    from zigma_amd import _lib
+    from zigma_amd.causal_conv1d_interface import causal_conv1d_raw
+    from zigma_amd.selective_scan_interface import conv_x_proj, conv_x_proj_eligible
+    rng = np.random.default_rng(L + Di)
+    xz = zo.bf16_round(rng.standard_normal((Bsz, L, 2 * Di)).astype(np.float32))       # x is the first half of the in_proj rows
+    cw = zo.bf16_round((rng.standard_normal((Di, 4)) * 0.5).astype(np.float32))
+    cb = zo.bf16_round((rng.standard_normal(Di) * 0.5).astype(np.float32))
+    w = zo.bf16_round((rng.standard_normal((Nn, Di)) * Di ** -0.5).astype(np.float32))
+    perm = {"id": np.arange(L), "rand": rng.permutation(L), "rev": np.arange(L)[::-1].copy(), "none": None}[order]
+    xzt = T(xz, torch.bfloat16)
+    x_half = xzt[:, :, :Di]
+    pt = None if perm is None else torch.tensor(perm, device="cuda", dtype=torch.int32)
+    cwt, cbt, wt = T(cw, torch.bfloat16), T(cb, torch.bfloat16), T(w, torch.bfloat16)
+    assert conv_x_proj_eligible(x_half, cwt, cbt, wt, pt) == (Bsz * L >= 16384)
+    u, x_dbl = conv_x_proj(x_half, cwt, cbt, wt, pt, _two_stage=two_stage)
+    assert _lib.last_kernel() == "conv_x_proj_mfma" and u.shape == (Bsz, L, Di) and x_dbl.shape == (Bsz, L, Nn)
+    xg = xz[:, :, :Di].astype(np.float64)
+    if perm is not None:
+        xg = xg[:, perm]
+    xp = np.concatenate([np.zeros((Bsz, 3, Di)), xg], axis=1)
+    pre = cb.astype(np.float64) + sum(cw[:, t].astype(np.float64) * xp[:, t:t + L] for t in range(4))
+    u_ref = zo.bf16_round((pre / (1.0 + np.exp(-pre))).astype(np.float32))
+    assert rel_err(N(u), u_ref) < 3e-3 and np.allclose(N(u), u_ref, rtol=2e-2, atol=2e-2)
+    xd_ref = zo.bf16_round((N(u).astype(np.float64) @ w.astype(np.float64).T).astype(np.float32))
+    assert rel_err(N(x_dbl), xd_ref) < 3e-3 and np.allclose(N(x_dbl), xd_ref, rtol=2e-2, atol=2e-2)
+    u_sep = torch.empty_like(u)
+    causal_conv1d_raw(x_half.transpose(1, 2), cwt, cbt, True, out=u_sep.transpose(1, 2), x_row_index=pt)
+    differ = (u_sep != u)
+    assert differ.float().mean().item() < 0.02
+    assert torch.allclose(u_sep.float(), u.float(), rtol=1e-2, atol=1e-3)
+
+
 @pytest.mark.parametrize("Bsz,L,H,NC", [(2, 100, 8, 77), (1, 64, 3, 128), (3, 17, 8, 5), (2, 256, 8, 81)])
 def test_cross_attn_kernel_vs_oracle(Bsz, L, H, NC):
     """softmax(scale Q K^T) V per head on the matrix cores vs a float64 numpy evaluation on the same bf16 operands; K / V

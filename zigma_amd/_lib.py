@@ -114,12 +114,18 @@ class XProjParams(C.Structure):
                 + [(n, i64) for n in ("x_row_stride", "w_row_stride", "out_row_stride")] + [(n, vp) for n in ("x", "w", "out")])
 
 
+class ConvXProjParams(C.Structure):
+    _fields_ = ([(n, i32) for n in ("batch", "seqlen", "dim", "n", "dtype", "flags")]
+                + [(n, i64) for n in ("x_batch_stride", "x_l_stride", "u_batch_stride", "u_l_stride", "w_row_stride", "out_row_stride")]
+                + [(n, vp) for n in ("x", "conv_weight", "conv_bias", "w", "u", "out", "x_row_index")])
+
+
 class LinearParams(C.Structure):
     _fields_ = ([("m", i64), ("n", i32), ("k", i32), ("dtype", i32), ("flags", i32), ("silu_from_col", i32), ("pad_", i32)]
                 + [(n, i64) for n in ("x_row_stride", "w_row_stride", "out_row_stride")] + [(n, vp) for n in ("x", "w", "bias", "out")])
 
 
-EXPORTS = ("zigma_linear_fwd", "zigma_selective_scan_fwd", "zigma_causal_conv1d_fwd", "zigma_add_norm_fwd", "zigma_dt_proj_softplus_fwd", "zigma_cross_attn_fwd", "zigma_x_proj_fwd", "zigma_selective_scan_bwd",
+EXPORTS = ("zigma_linear_fwd", "zigma_conv_x_proj_fwd", "zigma_selective_scan_fwd", "zigma_causal_conv1d_fwd", "zigma_add_norm_fwd", "zigma_dt_proj_softplus_fwd", "zigma_cross_attn_fwd", "zigma_x_proj_fwd", "zigma_selective_scan_bwd",
            "zigma_selective_scan_bwd_workspace_bytes", "zigma_causal_conv1d_bwd",
            "zigma_causal_conv1d_bwd_workspace_bytes", "zigma_add_norm_bwd", "zigma_add_norm_bwd_workspace_bytes",
            "zigma_strerror",

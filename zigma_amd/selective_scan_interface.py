@@ -16,6 +16,8 @@ Backward (SURVEY.md §8f rank 1): `scan_bwd_tok` binds zigma_selective_scan_bwd;
 form of `mamba_inner_tok` (MambaInnerFn.backward, :367-434) that the blocks use when autograd is recording.  The
 (B, D, L)-layout entry points (`selective_scan_fn`, `mamba_inner_fn`) stay forward-only.
 """
+import os
+
 import torch
 import torch.nn.functional as F
 
@@ -24,6 +26,8 @@ from .causal_conv1d_interface import causal_conv1d_raw, conv_bwd_tok
 
 
 SPLIT_SMALL_BATCH = True     # tools/latency_probe.py flips this to measure the effect of the small-batch sequence split
+# conv + SiLU + x_proj in one kernel (u written once, never read back): ZIGMA_CONV_XPROJ=0 pins the two separate kernels
+USE_CONV_X_PROJ = os.environ.get("ZIGMA_CONV_XPROJ", "1") != "0"
 USE_X_PROJ_KERNEL = True      # own MFMA kernel for the skinny x_proj instead of the library GEMM (same speed stand-alone)
 SPLIT_MAX_WGS = 200          # ... and sweeps this: split when batch * d_inner / 64 is at most this many workgroups (tools/split_threshold_probe.py)
 
@@ -190,6 +194,43 @@ def x_proj(u, weight):
     P.x, P.w, P.out = _lib.ptr(u2), _lib.ptr(weight), _lib.ptr(out)
     _lib.call("zigma_x_proj_fwd", P, dev)
     return out.reshape(*lead, n)
+
+
+def conv_x_proj_eligible(x_half, conv_w, conv_b, x_proj_weight, perm, reset_period=0):
+    """limits of zigma_conv_x_proj_fwd: bf16, width-4 taps as contiguous (d_inner, 4), a bias, seqlen % 32 == 0,
+    batch * seqlen % 256 == 0 and >= 16384 positions (a workgroup walks 256 positions over the whole d_inner: fewer than ~64
+    workgroups leave the chip idle), d_inner % 64 == 0, n <= 96, 16-byte aligned rows, one sequence per batch row."""
+    if conv_b is None or reset_period or not x_half.is_cuda:
+        return False
+    Bsz, L, Di = x_half.shape
+    return (x_half.dtype == torch.bfloat16 and conv_w.dtype == torch.bfloat16 and conv_b.dtype == torch.bfloat16
+            and x_proj_weight.dtype == torch.bfloat16 and conv_w.shape == (Di, 4) and conv_w.is_contiguous() and conv_b.is_contiguous()
+            and L % 32 == 0 and (Bsz * L) % 256 == 0 and Bsz * L >= 16384 and Di % 64 == 0 and x_proj_weight.shape[0] <= 96
+            and x_half.stride(2) == 1 and x_half.stride(1) % 8 == 0 and x_half.stride(0) % 8 == 0
+            and x_proj_weight.stride(1) == 1 and x_proj_weight.stride(0) % 8 == 0
+            and all(t.data_ptr() % 16 == 0 for t in (x_half, conv_w, conv_b, x_proj_weight))
+            and (perm is None or (perm.dtype == torch.int32 and perm.is_contiguous())))
+
+
+def conv_x_proj(x_half, conv_w, conv_b, x_proj_weight, perm=None, _two_stage=False):
+    """u = silu(causal_conv1d(x_half[:, perm])) and x_dbl = u @ x_proj_weight.T in one pass over x (zigma_conv_x_proj_fwd).
+    x_half: (B, L, d_inner) bf16 view with contiguous channels (the first half of the in_proj output, as is); conv_w: (d_inner, 4);
+    returns u (B, L, d_inner) in SCAN order and x_dbl (B, L, n).  Replaces causal_conv1d_fn + F.linear of reference
+    selective_scan_interface.py:307-322."""
+    dev = _lib.require_device(x_half, conv_w, conv_b, x_proj_weight, perm)
+    Bsz, L, Di = x_half.shape
+    n = x_proj_weight.shape[0]
+    u = torch.empty(Bsz, L, Di, device=x_half.device, dtype=x_half.dtype)
+    x_dbl = torch.empty(Bsz, L, n, device=x_half.device, dtype=x_half.dtype)
+    P = _lib.ConvXProjParams()
+    P.batch, P.seqlen, P.dim, P.n, P.dtype, P.flags = Bsz, L, Di, n, _lib.dtype_id(x_half), 1 if _two_stage else 0
+    P.x_batch_stride, P.x_l_stride = x_half.stride(0), x_half.stride(1)
+    P.u_batch_stride, P.u_l_stride = u.stride(0), u.stride(1)
+    P.w_row_stride, P.out_row_stride = x_proj_weight.stride(0), n
+    P.x, P.conv_weight, P.conv_bias, P.w = _lib.ptr(x_half), _lib.ptr(conv_w), _lib.ptr(conv_b), _lib.ptr(x_proj_weight)
+    P.u, P.out, P.x_row_index = _lib.ptr(u), _lib.ptr(x_dbl), _lib.ptr(perm)
+    _lib.call("zigma_conv_x_proj_fwd", P, dev)
+    return u, x_dbl
 
 
 def dt_proj_eligible(x_dbl, dt_rank, weight):
@@ -449,14 +490,17 @@ def mamba_inner_tok(xz, conv1d_weight, conv1d_bias, x_proj_weight, delta_proj_we
     N = A.shape[1]
     w = conv1d_weight.reshape(Di, -1)
     x_half, z_half = xz[:, :, :Di], xz[:, :, Di:]
-    # depthwise causal conv + SiLU over the reordered sequence; u is in SCAN order
-    u = torch.empty(Bsz, L, Di, device=xz.device, dtype=xz.dtype)
-    causal_conv1d_raw(x_half.transpose(1, 2), w, conv1d_bias, True, out=u.transpose(1, 2), x_row_index=perm,
-                      reset_period=reset_period)
-    if USE_X_PROJ_KERNEL and x_proj_eligible(u, x_proj_weight):
-        x_dbl = x_proj(u, x_proj_weight)                                 # (B, L, R + 2N)   read-bound MFMA kernel
+    if USE_CONV_X_PROJ and conv_x_proj_eligible(x_half, w, conv1d_bias, x_proj_weight, perm, reset_period):
+        u, x_dbl = conv_x_proj(x_half, w, conv1d_bias, x_proj_weight, perm)   # one pass: read x, write u (scan order) and x_dbl
     else:
-        x_dbl = F.linear(u, x_proj_weight)                               # (B, L, R + 2N)   GEMM
+        # depthwise causal conv + SiLU over the reordered sequence; u is in SCAN order
+        u = torch.empty(Bsz, L, Di, device=xz.device, dtype=xz.dtype)
+        causal_conv1d_raw(x_half.transpose(1, 2), w, conv1d_bias, True, out=u.transpose(1, 2), x_row_index=perm,
+                          reset_period=reset_period)
+        if USE_X_PROJ_KERNEL and x_proj_eligible(u, x_proj_weight):
+            x_dbl = x_proj(u, x_proj_weight)                             # (B, L, R + 2N)   read-bound MFMA kernel
+        else:
+            x_dbl = F.linear(u, x_proj_weight)                           # (B, L, R + 2N)   GEMM
     fused_dt = delta_softplus and dt_proj_eligible(x_dbl, R, delta_proj_weight)
     if fused_dt:   # K = dt_rank GEMM + bias + softplus in one write-bound MFMA kernel; scan skips its softplus
         delta = dt_proj_softplus(x_dbl, R, delta_proj_weight, delta_bias, True)
