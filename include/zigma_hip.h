@@ -389,7 +389,7 @@ int zigma_x_proj_fwd(const zigma_xproj_params_t *p, void *stream);
  * projection, as in the reference.  x: (batch, seqlen, dim) channel-contiguous rows; conv_weight: (dim, 4) contiguous;
  * conv_bias: (dim); w: (n, dim) rows; u: (batch, seqlen, dim) in scan order; out: (batch * seqlen, n) rows.
  * Limits: width 4, bias required, seqlen % 32 == 0, batch * seqlen % 256 == 0, dim % 64 == 0, n <= 96, 16-byte aligned rows.
- * flags: bit 0 = two LDS stages instead of three (probe).
+ * flags: 0; probes: 1 = three LDS stages, 2 = eight-wave workgroups, 4 / 8 = phases skipped (results wrong).
  * ------------------------------------------------------------------------------------------ */
 typedef struct zigma_conv_xproj_params {
     int32_t batch, seqlen, dim, n;

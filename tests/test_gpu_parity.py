@@ -500,11 +500,11 @@ def test_x_proj_kernel_vs_oracle(M, K, Nn):
     assert rel_err(N(out), ref) < 3e-3 and np.allclose(N(out), ref, rtol=2e-2, atol=2e-2)
 
 
-@pytest.mark.parametrize("Bsz,L,Di,Nn,order,two_stage", [(2, 128, 64, 72, "id", False), (1, 256, 192, 40, "rand", False),
-                                                       (16, 1024, 1280, 72, "rand", False), (64, 256, 128, 96, "none", False),
-                                                       (4, 4096, 640, 72, "rev", True)])
-def test_conv_x_proj_kernel_vs_oracle(Bsz, L, Di, Nn, order, two_stage):
-    """The one-pass conv + SiLU + x_proj kernel vs float64 numpy on the same bf16 operands: u (bf16-rounded conv output in scan
+@pytest.mark.parametrize("Bsz,L,Di,Nn,order,flags", [(2, 128, 64, 72, "id", 0), (1, 256, 192, 40, "rand", 0), (1, 256, 192, 40, "rand", 3),
+                                                   (16, 1024, 1280, 72, "rand", 0), (64, 256, 128, 96, "none", 1),
+                                                   (4, 4096, 640, 72, "rev", 2), (8, 32, 64, 72, "rand", 0)])
+def test_conv_x_proj_kernel_vs_oracle(Bsz, L, Di, Nn, order, flags):
+    """The one-pass conv + SiLU + x_proj kernel (flags: 0 = shipped form, 1 / 2 / 3 = three stages / 8-wave workgroups) vs float64 numpy on the same bf16 operands: u (bf16-rounded conv output in scan
     order) and x_dbl = u @ W_x^T evaluated on the kernel's OWN u (the reference rounds u to bf16 before the projection too);
     and against the two separate kernels (same u up to single bf16 roundings of an fp32 sum associated differently)."""
     from zigma_amd import _lib
@@ -521,7 +521,7 @@ def test_conv_x_proj_kernel_vs_oracle(Bsz, L, Di, Nn, order, two_stage):
     pt = None if perm is None else torch.tensor(perm, device="cuda", dtype=torch.int32)
     cwt, cbt, wt = T(cw, torch.bfloat16), T(cb, torch.bfloat16), T(w, torch.bfloat16)
     assert conv_x_proj_eligible(x_half, cwt, cbt, wt, pt) == (Bsz * L >= 16384)
-    u, x_dbl = conv_x_proj(x_half, cwt, cbt, wt, pt, _two_stage=two_stage)
+    u, x_dbl = conv_x_proj(x_half, cwt, cbt, wt, pt, _flags=flags)
     assert _lib.last_kernel() == "conv_x_proj_mfma" and u.shape == (Bsz, L, Di) and x_dbl.shape == (Bsz, L, Nn)
     xg = xz[:, :, :Di].astype(np.float64)
     if perm is not None:

@@ -7,6 +7,7 @@ cd $R
 timeout 300 python -m pytest tests -m gpu -q 2>&1 | grep -v Warning | tail -4 > $O/gpu_tests.txt
 timeout 200 python bench.py > $O/bench_default_line.json 2> $O/bench_default.err
 timeout 120 python tools/scan_ab.py > $O/scan_ab.json 2>/dev/null
+timeout 120 python tools/conv_xproj_ab.py 2>/dev/null | grep "^{" > $O/conv_xproj_ab.json
 timeout 200 python tools/linear_probe.py 2>/dev/null | grep "^{" > $O/linear_probe.jsonl
 timeout 250 python tools/run_configs.py 2>/dev/null > $O/configs_3_4_5.jsonl
 bash tools/prof_bench.sh > $O/prof_bench_top.txt 2>&1

@@ -20,8 +20,9 @@ def separate():
     return u_sep, x_proj(u_sep, w)
 
 
-variants = {"separate": separate, "fused3": lambda: conv_x_proj(x_half, cw, cb, w, perm),
-            "fused2": lambda: conv_x_proj(x_half, cw, cb, w, perm, _two_stage=True)}
+F = lambda fl: (lambda: conv_x_proj(x_half, cw, cb, w, perm, _flags=fl))
+variants = {"separate": separate, "fused": F(0), "fused_3stage": F(1), "fused_8w": F(2), "fused_8w_3stage": F(3),
+            "probe_nostore": F(4), "probe_noconv": F(8), "probe_neither": F(12)}
 outs = {k: f() for k, f in variants.items()}
 torch.cuda.synchronize()
 times = {k: [] for k in variants}
@@ -36,7 +37,7 @@ for rnd in range(6):
 by = B * L * Di * 2 * 2 + B * L * n * 2
 res = dict(shape=f"B={B} L={L} Di={Di} n={n} bf16", us_median={k: sorted(v)[len(v) // 2] for k, v in times.items()},
            us_min={k: min(v) for k, v in times.items()},
-           hbm_frac_of_8TBps_fused={k: by / (sorted(times[k])[3] * 1e-6) / 8e12 for k in ("fused3", "fused2")},
-           u_mismatch_frac=float((outs["fused3"][0] != outs["separate"][0]).float().mean()),
-           xdbl_max_abs_diff=float((outs["fused3"][1].float() - outs["separate"][1].float()).abs().max()))
+           hbm_frac_of_8TBps_fused={k: by / (sorted(times[k])[3] * 1e-6) / 8e12 for k in ("fused", "fused_3stage", "fused_8w", "fused_8w_3stage")},
+           u_mismatch_frac=float((outs["fused"][0] != outs["separate"][0]).float().mean()),
+           xdbl_max_abs_diff=float((outs["fused"][1].float() - outs["separate"][1].float()).abs().max()))
 print(json.dumps(res))

@@ -7,14 +7,17 @@
 // here u is produced in registers in exactly the MFMA A-fragment layout of the projection, so it is written once (the scan
 // needs it) and never read back:  read x + write u.
 //
-//   workgroup = 256 positions (scan order) = 8 waves x 32 positions; K = d_inner is walked in stages of 64 channels.
-//   Per stage every wave fetches ITS 35 input rows (3 halo + 32, picked through the row table, one full 128-byte line each)
-//   straight into LDS (global_load_lds_dwordx4, source-side swizzle), the workgroup shares one 64-channel slab of W_x (n rows
-//   x 128 B) and of the conv taps/bias; stage s + 1 is in flight while stage s is consumed.
+//   workgroup = 128 positions (scan order) = 4 waves x 32 positions, two workgroups per CU; K = d_inner is walked in stages of
+//   64 channels.  Per stage every wave fetches ITS 35 input rows (3 halo + 32, picked through the row table, one full 128-byte
+//   line each) straight into LDS (global_load_lds_dwordx4, source-side swizzle), the workgroup shares one 64-channel slab of W_x
+//   (n rows x 128 B) and of the conv taps/bias; stage s + 1 is in flight while stage s is consumed.
 //   A lane = (position j, 8 adjacent channels): the four taps are the LDS rows j .. j+3 of its own channels (no cross-lane
 //   traffic), the conv is 2 x v_dot2c_f32_bf16 per channel on (tap, tap) pairs built with v_perm_b32 against the taps as they
-//   lie in the (d_inner, 4) bf16 weight, SiLU, pack: the 8 bf16 are at once the 16-byte store of u and the A fragment of
-//   v_mfma_f32_32x32x16_bf16 against the W_x slab (32 x 96 fp32 accumulator per wave, rows beyond n are never stored).
+//   lie in the (d_inner, 4) bf16 weight, SiLU, pack: the 8 bf16 are the A fragment of v_mfma_f32_32x32x16_bf16 against the W_x
+//   slab (32 x 96 fp32 accumulator per wave, rows beyond n are never stored); u leaves once per stage as full 128-byte lines,
+//   transposed through the wave's own (consumed) input rows.
+// Measured at the headline shape (B=64, L=1024, d_inner=1280, n=72): 72 us against 131 us for conv_tok + x_proj_mfma
+// (tools/conv_xproj_ab.py); loads + MFMA alone 35 us, + conv 64 us, + stores 64 us (probe flags).
 // bf16 only; width 4; bias required; seqlen % 32 == 0; d_inner % 64 == 0; n <= 96.
 #include "zigma_common.h"
 
@@ -26,11 +29,12 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __attribute__((address_space(3))) unsigned char *lds_ptr_t;
 typedef const __attribute__((address_space(1))) void *gbl_ptr_t;
 
-constexpr int kCxWaves = 8, kCxTok = 32, kCxBK = 64, kCxHalo = 3;
+constexpr int kCxTok = 32, kCxBK = 64, kCxHalo = 3;
 constexpr int kCxXBytes = 40 * 128;                                  // per wave and stage: 35 rows used, 5 load instructions
-constexpr int kCxWOff = kCxWaves * kCxXBytes;                        // W_x slab: 96 rows x 128 B
-constexpr int kCxCOff = kCxWOff + 96 * 128;                          // conv taps (64 ch x 8 B) + bias (64 x 2 B), 1 KB
-constexpr int kCxStage = kCxCOff + 1024;                             // 54272 B
+// stage layout for NW waves: [NW x input rows][W_x slab: 96 rows x 128 B][conv taps (64 ch x 8 B) + bias (64 x 2 B), 1 KB]
+constexpr int cx_w_off(int nw) { return nw * kCxXBytes; }
+constexpr int cx_c_off(int nw) { return cx_w_off(nw) + 96 * 128; }
+constexpr int cx_stage(int nw) { return cx_c_off(nw) + 1024; }      // 8 waves: 54272 B, 4 waves: 33792 B
 
 __device__ __forceinline__ float bf_lo(unsigned v) { return __uint_as_float(v << 16); }
 __device__ __forceinline__ float bf_hi(unsigned v) { return __uint_as_float(v & 0xffff0000u); }
@@ -76,9 +80,11 @@ __device__ __forceinline__ void wait_vm_n(int n) {
     }
 }
 
-template <int NST>
-__global__ __launch_bounds__(64 * kCxWaves) void conv_x_proj_kernel(const zigma_conv_xproj_params_t p) {
+template <int NST, int NW>
+__global__ __launch_bounds__(64 * NW) void conv_x_proj_kernel(const zigma_conv_xproj_params_t p) {
+    constexpr int kCxWaves = NW, kCxWOff = cx_w_off(NW), kCxCOff = cx_c_off(NW), kCxStage = cx_stage(NW), NWI = (12 + NW - 1) / NW;
     __shared__ __attribute__((aligned(1024))) unsigned char smem[NST * kCxStage];
+    const int dbg = p.flags;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int j = lane & 31, kh = lane >> 5;
@@ -102,13 +108,15 @@ __global__ __launch_bounds__(64 * kCxWaves) void conv_x_proj_kernel(const zigma_
             xsrc[i] = xb + static_cast<int64_t>(row) * p.x_l_stride * 2 + (((lane & 7) ^ ((rr >> 1) & 7)) << 4);
         }
     }
-    const bool w_second = (wave + 8) * 8 < p.n;                        // wave-uniform: rows 64.. of W_x
-    const unsigned char *wsrc[2];
+    // W_x slab: 8 rows per load instruction, instruction q = wave + NW i (wave-uniform: skipped when its rows are all beyond n)
+    const unsigned char *wsrc[NWI];
+    int n_w = 0;
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        int row = (wave + 8 * i) * 8 + (lane >> 3);
+    for (int i = 0; i < NWI; ++i) {
+        int row = (wave + NW * i) * 8 + (lane >> 3);
         row = row < p.n ? row : p.n - 1;
         wsrc[i] = reinterpret_cast<const unsigned char *>(p.w) + static_cast<int64_t>(row) * p.w_row_stride * 2 + (((lane & 7) ^ ((row >> 1) & 7)) << 4);
+        n_w += (wave + NW * i) * 8 < p.n ? 1 : 0;
     }
     // conv taps / bias slab (wave 1): lanes 0..31 taps of 2 channels each, lanes 32..39 bias of 8 channels each
     const unsigned char *csrc = lane < 32 ? reinterpret_cast<const unsigned char *>(p.conv_weight) + lane * 16
@@ -120,20 +128,26 @@ __global__ __launch_bounds__(64 * kCxWaves) void conv_x_proj_kernel(const zigma_
 #pragma unroll
         for (int i = 0; i < 5; ++i)
             __builtin_amdgcn_global_load_lds((gbl_ptr_t)(xsrc[i] + st * (kCxBK * 2)), (lds_ptr_t)(dst) + wave * kCxXBytes + i * 1024, 16, 0, 0);
-        __builtin_amdgcn_global_load_lds((gbl_ptr_t)(wsrc[0] + st * (kCxBK * 2)), (lds_ptr_t)(dst) + kCxWOff + wave * 1024, 16, 0, 0);
-        if (w_second)
-            __builtin_amdgcn_global_load_lds((gbl_ptr_t)(wsrc[1] + st * (kCxBK * 2)), (lds_ptr_t)(dst) + kCxWOff + (wave + 8) * 1024, 16, 0, 0);
+#pragma unroll
+        for (int i = 0; i < NWI; ++i)
+            if (i < n_w)
+                __builtin_amdgcn_global_load_lds((gbl_ptr_t)(wsrc[i] + st * (kCxBK * 2)), (lds_ptr_t)(dst) + kCxWOff + (wave + NW * i) * 1024, 16, 0, 0);
         if (wave == 1)
             __builtin_amdgcn_global_load_lds((gbl_ptr_t)(csrc + static_cast<int64_t>(st) * c_step), (lds_ptr_t)(dst) + kCxCOff, 16, 0, 0);
     };
 
-    const int nld = 6 + (w_second ? 1 : 0) + (wave == 1 ? 1 : 0);            // load instructions this wave issues per stage
+    const int nld = 5 + n_w + (wave == 1 ? 1 : 0);                      // load instructions this wave issues per stage
 
     f32x16 acc[3];
 #pragma unroll
     for (int nb = 0; nb < 3; ++nb) acc[nb] = f32x16{};
 
-    unsigned char *urow = reinterpret_cast<unsigned char *>(p.u) + (static_cast<int64_t>(b) * p.u_batch_stride + static_cast<int64_t>(t0 + j) * p.u_l_stride) * 2 + kh * 16;
+    // u stores: lane -> (row lane >> 3 of every group of 8, 16-byte piece lane & 7) of the transposed tile
+    const int64_t u_pitch = p.u_l_stride * 2;
+    unsigned char *ust = reinterpret_cast<unsigned char *>(p.u) + static_cast<int64_t>(b) * p.u_batch_stride * 2 + (t0 + (lane >> 3)) * u_pitch + (lane & 7) * 16;
+    const unsigned u_wr = wave * kCxXBytes + j * 128 + ((kh ^ ((j >> 1) & 7)) << 4);                     // row j, slot ((ks << 1) | kh) ^ swizzle
+    // read back rows i * 8 + (lane >> 3), piece lane & 7: (row >> 1) & 7 == (lane >> 4) ^ ((i & 1) << 2), the i part is applied at the read
+    const unsigned u_rd = wave * kCxXBytes + (lane >> 3) * 128 + (((lane & 7) ^ (lane >> 4)) << 4);
     unsigned x_off[4];                                                 // this wave's rows j .. j+3, piece kh, swizzled
 #pragma unroll
     for (int s = 0; s < 4; ++s) x_off[s] = wave * kCxXBytes + (j + s) * 128 + ((kh ^ (((j + s) >> 1) & 7)) << 4);
@@ -150,7 +164,7 @@ __global__ __launch_bounds__(64 * kCxWaves) void conv_x_proj_kernel(const zigma_
         // VM_CNT retires in issue order; what may stay in flight behind stage st's loads: the loads of the younger stages and the
         // u stores (4 per stage) issued after them
         {
-            const int st_stores = 4 * (st < NST - 1 ? st : NST - 1);
+            const int st_stores = (dbg & 4) ? 0 : 4 * (st < NST - 1 ? st : NST - 1);
             const int younger_loads = n_stages - 1 - st < NST - 2 ? n_stages - 1 - st : NST - 2;
             wait_vm_n(st_stores + nld * younger_loads);
         }
@@ -168,6 +182,7 @@ __global__ __launch_bounds__(64 * kCxWaves) void conv_x_proj_kernel(const zigma_
             for (int nb = 0; nb < 3; ++nb) lds_rd(k.Bf[nb], (sb + w_off + nb * 32 * 128) ^ (ks << 5));
         };
         KStep kb[2];
+        u32x4 uq[kCxBK / 16];
         reads(kb[0], 0);
 #pragma unroll
         for (int ks = 0; ks < kCxBK / 16; ++ks) {
@@ -186,7 +201,8 @@ __global__ __launch_bounds__(64 * kCxWaves) void conv_x_proj_kernel(const zigma_
             const unsigned xs[4][4] = {{k.X[0].x, k.X[0].y, k.X[0].z, k.X[0].w}, {k.X[1].x, k.X[1].y, k.X[1].z, k.X[1].w},
                                        {k.X[2].x, k.X[2].y, k.X[2].z, k.X[2].w}, {k.X[3].x, k.X[3].y, k.X[3].z, k.X[3].w}};
             const unsigned bs[4] = {k.Bc.x, k.Bc.y, k.Bc.z, k.Bc.w};
-            unsigned ur[4];
+            unsigned ur[4] = {xs[3][0], xs[3][1], xs[3][2], xs[3][3]};
+            if (!(dbg & 8))
 #pragma unroll
             for (int r = 0; r < 4; ++r) {                              // channels 2r (low halves) and 2r + 1 (high halves)
                 const unsigned lo01 = __builtin_amdgcn_perm(xs[1][r], xs[0][r], 0x05040100u);
@@ -200,11 +216,26 @@ __global__ __launch_bounds__(64 * kCxWaves) void conv_x_proj_kernel(const zigma_
                 ur[r] = pack_bf2(silu(a_lo), silu(a_hi));
             }
             const u32x4 u8 = {ur[0], ur[1], ur[2], ur[3]};
-            *reinterpret_cast<u32x4 *>(urow + (st * kCxBK + ks * 16) * 2) = u8;
+            uq[ks] = u8;
             const bf16x8 a = __builtin_bit_cast(bf16x8, u8);
 #pragma unroll
             for (int nb = 0; nb < 3; ++nb)
                 acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, __builtin_bit_cast(bf16x8, k.Bf[nb]), acc[nb], 0, 0, 0);
+        }
+        // u of this stage (32 positions x 64 channels per wave) leaves as FULL 128-byte lines: a lane holds 16-byte pieces of its own
+        // row only (two lanes = 32 contiguous bytes per store instruction and row — measured: the partial-line stores cost more than
+        // the loads), so the wave transposes through its own input rows of this stage (every read of them has been settled above; the
+        // region is wave-private and the LDS queue of a wave is in order: no barrier).
+        if (!(dbg & 4)) {
+#pragma unroll
+            for (int ks = 0; ks < kCxBK / 16; ++ks)
+                asm volatile("ds_write_b128 %0, %1" ::"v"((sb + u_wr) ^ (ks << 5)), "v"(uq[ks]) : "memory");
+            u32x4 t[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) lds_rd(t[i], (sb + u_rd + i * 1024) ^ ((i & 1) << 6));
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(t[0]), "+v"(t[1]), "+v"(t[2]), "+v"(t[3]));
+#pragma unroll
+            for (int i = 0; i < 4; ++i) *reinterpret_cast<u32x4 *>(ust + static_cast<int64_t>(i * 8) * u_pitch + st * (kCxBK * 2)) = t[i];
         }
     }
     // C/D layout: column = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
@@ -229,20 +260,31 @@ extern "C" int zigma_conv_x_proj_fwd(const zigma_conv_xproj_params_t *pp, void *
     (void)hipGetLastError();
     const zigma_conv_xproj_params_t &p = *pp;
     if (p.batch < 0 || p.seqlen < 0 || p.dim < 1 || p.n < 1) return ZIGMA_ERR_SHAPE;
-    if (p.flags & ~1) return ZIGMA_ERR_UNSUPPORTED;
+    if (p.flags & ~15) return ZIGMA_ERR_UNSUPPORTED;
     if (p.batch == 0 || p.seqlen == 0) return ZIGMA_OK;
     if (!p.x || !p.conv_weight || !p.conv_bias || !p.w || !p.u || !p.out) return ZIGMA_ERR_NULL;
     if (p.dtype != ZIGMA_BF16) return ZIGMA_ERR_DTYPE;
     if (p.n > 96 || p.dim % kCxBK != 0 || p.seqlen % kCxTok != 0) return ZIGMA_ERR_SHAPE;
     const int64_t m = static_cast<int64_t>(p.batch) * p.seqlen;
-    if (m % (kCxTok * kCxWaves) != 0) return ZIGMA_ERR_SHAPE;
+    if (m % (kCxTok * 8) != 0) return ZIGMA_ERR_SHAPE;       // (either workgroup size)
     auto al16 = [](const void *q) { return reinterpret_cast<uintptr_t>(q) % 16 == 0; };
     if (p.x_l_stride % 8 != 0 || p.x_batch_stride % 8 != 0 || p.u_l_stride % 8 != 0 || p.u_batch_stride % 8 != 0 || p.w_row_stride % 8 != 0 ||
         !al16(p.x) || !al16(p.u) || !al16(p.w) || !al16(p.conv_weight) || !al16(p.conv_bias))
         return ZIGMA_ERR_STRIDE;
-    const dim3 grid(static_cast<unsigned>(m / (kCxTok * kCxWaves))), block(64 * kCxWaves);
-    if (p.flags & 1) hipLaunchKernelGGL(conv_x_proj_kernel<2>, grid, block, 0, static_cast<hipStream_t>(stream_), p);
-    else hipLaunchKernelGGL(conv_x_proj_kernel<3>, grid, block, 0, static_cast<hipStream_t>(stream_), p);
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    // default: 4-wave workgroups (128 positions), two stages = 66 KB of LDS: two workgroups per CU that drift apart, one computing
+    // while the other waits for its loads (measured 72 us; 8 waves in lockstep 75 us; a third stage does not pay, the second
+    // workgroup does its job).  flags: 1 = three stages, 2 = eight-wave workgroups; probes (wrong results): 4 = no u stores,
+    // 8 = no conv arithmetic.
+    if (p.flags & 2) {
+        const dim3 grid(static_cast<unsigned>(m / (kCxTok * 8))), block(64 * 8);
+        if (p.flags & 1) hipLaunchKernelGGL((conv_x_proj_kernel<3, 8>), grid, block, 0, stream, p);
+        else hipLaunchKernelGGL((conv_x_proj_kernel<2, 8>), grid, block, 0, stream, p);
+    } else {
+        const dim3 grid(static_cast<unsigned>(m / (kCxTok * 4))), block(64 * 4);
+        if (p.flags & 1) hipLaunchKernelGGL((conv_x_proj_kernel<3, 4>), grid, block, 0, stream, p);
+        else hipLaunchKernelGGL((conv_x_proj_kernel<2, 4>), grid, block, 0, stream, p);
+    }
     set_last_kernel("conv_x_proj_mfma");
     return check_launch();
 }

@@ -212,7 +212,7 @@ def conv_x_proj_eligible(x_half, conv_w, conv_b, x_proj_weight, perm, reset_peri
             and (perm is None or (perm.dtype == torch.int32 and perm.is_contiguous())))
 
 
-def conv_x_proj(x_half, conv_w, conv_b, x_proj_weight, perm=None, _two_stage=False):
+def conv_x_proj(x_half, conv_w, conv_b, x_proj_weight, perm=None, _flags=0):
     """u = silu(causal_conv1d(x_half[:, perm])) and x_dbl = u @ x_proj_weight.T in one pass over x (zigma_conv_x_proj_fwd).
     x_half: (B, L, d_inner) bf16 view with contiguous channels (the first half of the in_proj output, as is); conv_w: (d_inner, 4);
     returns u (B, L, d_inner) in SCAN order and x_dbl (B, L, n).  Replaces causal_conv1d_fn + F.linear of reference
@@ -223,7 +223,7 @@ def conv_x_proj(x_half, conv_w, conv_b, x_proj_weight, perm=None, _two_stage=Fal
     u = torch.empty(Bsz, L, Di, device=x_half.device, dtype=x_half.dtype)
     x_dbl = torch.empty(Bsz, L, n, device=x_half.device, dtype=x_half.dtype)
     P = _lib.ConvXProjParams()
-    P.batch, P.seqlen, P.dim, P.n, P.dtype, P.flags = Bsz, L, Di, n, _lib.dtype_id(x_half), 1 if _two_stage else 0
+    P.batch, P.seqlen, P.dim, P.n, P.dtype, P.flags = Bsz, L, Di, n, _lib.dtype_id(x_half), _flags
     P.x_batch_stride, P.x_l_stride = x_half.stride(0), x_half.stride(1)
     P.u_batch_stride, P.u_l_stride = u.stride(0), u.stride(1)
     P.w_row_stride, P.out_row_stride = x_proj_weight.stride(0), n
