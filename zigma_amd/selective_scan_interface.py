@@ -28,6 +28,7 @@ from .causal_conv1d_interface import causal_conv1d_raw, conv_bwd_tok
 SPLIT_SMALL_BATCH = True     # tools/latency_probe.py flips this to measure the effect of the small-batch sequence split
 # conv + SiLU + x_proj in one kernel (u written once, never read back): ZIGMA_CONV_XPROJ=0 pins the two separate kernels
 USE_CONV_X_PROJ = os.environ.get("ZIGMA_CONV_XPROJ", "1") != "0"
+CONV_X_PROJ_MIN_POSITIONS = int(os.environ.get("ZIGMA_CONV_XPROJ_MIN", "16384"))   # below: too few workgroups (128 positions each)
 USE_X_PROJ_KERNEL = True      # own MFMA kernel for the skinny x_proj instead of the library GEMM (same speed stand-alone)
 SPLIT_MAX_WGS = 200          # ... and sweeps this: split when batch * d_inner / 64 is at most this many workgroups (tools/split_threshold_probe.py)
 
@@ -205,7 +206,7 @@ def conv_x_proj_eligible(x_half, conv_w, conv_b, x_proj_weight, perm, reset_peri
     Bsz, L, Di = x_half.shape
     return (x_half.dtype == torch.bfloat16 and conv_w.dtype == torch.bfloat16 and conv_b.dtype == torch.bfloat16
             and x_proj_weight.dtype == torch.bfloat16 and conv_w.shape == (Di, 4) and conv_w.is_contiguous() and conv_b.is_contiguous()
-            and L % 32 == 0 and (Bsz * L) % 256 == 0 and Bsz * L >= 16384 and Di % 64 == 0 and x_proj_weight.shape[0] <= 96
+            and L % 32 == 0 and (Bsz * L) % 256 == 0 and Bsz * L >= CONV_X_PROJ_MIN_POSITIONS and Di % 64 == 0 and x_proj_weight.shape[0] <= 96
             and x_half.stride(2) == 1 and x_half.stride(1) % 8 == 0 and x_half.stride(0) % 8 == 0
             and x_proj_weight.stride(1) == 1 and x_proj_weight.stride(0) % 8 == 0
             and all(t.data_ptr() % 16 == 0 for t in (x_half, conv_w, conv_b, x_proj_weight))
