@@ -147,7 +147,7 @@ def lib():
                          ("zigma_add_norm_fwd", NormParams), ("zigma_dt_proj_softplus_fwd", DtProjParams),
                          ("zigma_selective_scan_bwd", ScanBwdParams), ("zigma_causal_conv1d_bwd", ConvBwdParams),
                          ("zigma_add_norm_bwd", NormBwdParams), ("zigma_cross_attn_fwd", XAttnParams), ("zigma_x_proj_fwd", XProjParams),
-                         ("zigma_linear_fwd", LinearParams)):
+                         ("zigma_linear_fwd", LinearParams), ("zigma_conv_x_proj_fwd", ConvXProjParams)):
             fn = getattr(L, name)
             fn.argtypes = [C.POINTER(st), vp]
             fn.restype = C.c_int

@@ -20,7 +20,11 @@ namespace zigma {
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-constexpr int kDtTokPerWave = 32, kDtChPerBlock = 64, kDtWaves = 4, kDtIters = 4;
+constexpr int kDtTokPerWave = 32, kDtChPerBlock = 64, kDtWaves = 4;
+#ifndef ZIGMA_DT_ITERS
+#define ZIGMA_DT_ITERS 4
+#endif
+constexpr int kDtIters = ZIGMA_DT_ITERS;
 
 __global__ __launch_bounds__(64 * kDtWaves) void dt_proj_softplus_kernel(const zigma_dtproj_params_t p) {
     const int lane = threadIdx.x & 63;
@@ -51,19 +55,27 @@ __global__ __launch_bounds__(64 * kDtWaves) void dt_proj_softplus_kernel(const z
     const float b_e = bias ? bias[d0 + 2 * j] : 0.f, b_o = bias ? bias[d0 + 2 * j + 1] : 0.f;
 
     const int64_t m_blk = static_cast<int64_t>(blockIdx.y) * (kDtTokPerWave * kDtWaves * kDtIters);
+    // A fragments of tile `it`: the next tile's are requested before this tile's softplus / stores (their L2 latency otherwise
+    // sits between every two tiles of a wave)
+    auto a_frags = [&](int it, bf16x8 (&a)[3]) {
+        int64_t mr = m_blk + (static_cast<int64_t>(it) * kDtWaves + wave) * kDtTokPerWave + j;
+        mr = mr < p.m ? mr : p.m - 1;                            // rows beyond m: clamped loads, never stored
+        const uint16_t *xr = xw + mr * p.x_row_stride;
+#pragma unroll
+        for (int s = 0; s < 3; ++s) a[s] = frag(xr, s * 16 + kh * 8);
+    };
+    bf16x8 a_cur[3], a_nxt[3];
+    a_frags(0, a_cur);
 #pragma unroll 1
     for (int it = 0; it < kDtIters; ++it) {
         const int64_t m0 = m_blk + (static_cast<int64_t>(it) * kDtWaves + wave) * kDtTokPerWave;
         if (m0 >= p.m) break;
-        int64_t mr = m0 + j;                                    // A fragment row (token) of this lane
-        if (mr >= p.m) mr = p.m - 1;
-        const uint16_t *xr = xw + mr * p.x_row_stride;
+        if (it + 1 < kDtIters) a_frags(it + 1, a_nxt);
         f32x16 ce = {}, co = {};
 #pragma unroll
         for (int s = 0; s < 3; ++s) {
-            const bf16x8 a = frag(xr, s * 16 + kh * 8);
-            ce = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, be[s], ce, 0, 0, 0);
-            co = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bo[s], co, 0, 0, 0);
+            ce = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_cur[s], be[s], ce, 0, 0, 0);
+            co = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_cur[s], bo[s], co, 0, 0, 0);
         }
         // C/D layout: column = lane & 31 (channel pair j), row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5) (token)
         const bool full = m0 + kDtTokPerWave <= p.m;            // wave-uniform: whole tile inside -> no per-store predicate
@@ -76,6 +88,8 @@ __global__ __launch_bounds__(64 * kDtWaves) void dt_proj_softplus_kernel(const z
             const uint32_t pk = static_cast<uint32_t>(from_float<BF16>(ve)) | (static_cast<uint32_t>(from_float<BF16>(vo)) << 16);
             if (full || m0 + 4 * kh + dm < p.m) *reinterpret_cast<uint32_t *>(orow + dm * p.out_row_stride) = pk;
         }
+#pragma unroll
+        for (int s = 0; s < 3; ++s) a_cur[s] = a_nxt[s];
     }
 }
 
