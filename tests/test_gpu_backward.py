@@ -279,6 +279,41 @@ def test_mamba_inner_tok_row_tables_match_explicit_gather_scatter():
         assert rel_err(N(a), N(t.grad)) < 1e-5
 
 
+def test_mamba_inner_tok_train_with_the_one_pass_conv_x_proj(monkeypatch):
+    """The differentiable Mamba inner at a size where its forward takes the one-pass conv + x_proj kernel (bf16, 16 384 positions)
+    vs the same op with the two separate kernels: same output and gradients up to bf16 roundings (u differs by single ulps in a
+    few elements per million; everything downstream sees that)."""
+    import zigma_amd.selective_scan_interface as ssi
+    from zigma_amd import _lib
+    g = torch.Generator(device="cpu").manual_seed(11)
+    Bsz, L, Di, R, Nst = 16, 1024, 128, 8, 16
+    bf = torch.bfloat16
+    mk = lambda *s, sc=1.0, dt=bf: (torch.randn(*s, generator=g) * sc).to(DEV, dt).requires_grad_(True)
+    xz, cw, cb = mk(Bsz, L, 2 * Di), mk(Di, 1, 4, sc=0.5), mk(Di, sc=0.1)
+    xw, dw = mk(R + 2 * Nst, Di, sc=Di ** -0.5), mk(Di, R, sc=R ** -0.5)
+    A = (-torch.exp(torch.randn(Di, Nst, generator=g) * 0.5)).to(DEV).requires_grad_(True)
+    D, db = mk(Di, dt=torch.float32), (torch.rand(Di, generator=g) * 0.5).to(DEV).requires_grad_(True)
+    perm = torch.randperm(L, generator=g).to(DEV, torch.int32)
+    wgt = torch.randn(Bsz, L, Di, generator=g).to(DEV, bf)
+    leaves = (xz, cw, cb, xw, dw, A, D, db)
+    seen = []
+    real = ssi.conv_x_proj
+    monkeypatch.setattr(ssi, "conv_x_proj", lambda *a, **k: (seen.append(1), real(*a, **k))[1])
+    res = []
+    for fused in (True, False):
+        monkeypatch.setattr(ssi, "USE_CONV_X_PROJ", fused)
+        for t in leaves:
+            t.grad = None
+        y = ssi.mamba_inner_tok(xz, cw, cb, xw, dw, A, D, db, perm=perm)
+        (y.float() * wgt.float()).sum().backward()
+        res.append((y.detach().float(), [t.grad.detach().float().clone() for t in leaves]))
+    assert len(seen) == 1                                            # taken with the switch on, not with it off
+    (y1, g1), (y2, g2) = res
+    assert rel_err(N(y1), N(y2)) < 2e-3
+    for a, b in zip(g1, g2):
+        assert rel_err(N(a), N(b)) < 1e-2
+
+
 def test_likelihood_sampler_runs_through_hip_backward():
     """Sampler.sample_ode_likelihood needs a vjp through the denoiser at every function evaluation: here it goes through
     LayerNormFn / MambaInnerTokFn (HIP forward + backward).  Checked against a finite-difference divergence probe."""

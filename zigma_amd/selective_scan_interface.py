@@ -352,9 +352,12 @@ class MambaInnerTokFn(torch.autograd.Function):
         Di, R, N = C2 // 2, dt_proj_w.shape[1], A.shape[1]
         w = conv_w.reshape(Di, -1)
         x_half, z_half = xz[:, :, :Di], xz[:, :, Di:]
-        u = torch.empty(Bsz, L, Di, device=xz.device, dtype=xz.dtype)
-        causal_conv1d_raw(x_half.transpose(1, 2), w, conv_b, True, out=u.transpose(1, 2), x_row_index=perm)
-        x_dbl = F.linear(u, x_proj_w)
+        if USE_CONV_X_PROJ and conv_x_proj_eligible(x_half, w, conv_b, x_proj_w, perm):
+            u, x_dbl = conv_x_proj(x_half, w, conv_b, x_proj_w, perm)      # one pass; the backward takes u and x_dbl as saved
+        else:
+            u = torch.empty(Bsz, L, Di, device=xz.device, dtype=xz.dtype)
+            causal_conv1d_raw(x_half.transpose(1, 2), w, conv_b, True, out=u.transpose(1, 2), x_row_index=perm)
+            x_dbl = F.linear(u, x_proj_w)
         delta = F.linear(x_dbl[:, :, :R], dt_proj_w)
         Bm, Cm = x_dbl[:, :, R:R + N], x_dbl[:, :, R + N:R + 2 * N]
         out = torch.empty(Bsz, L, Di, device=xz.device, dtype=xz.dtype)
