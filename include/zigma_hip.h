@@ -388,7 +388,8 @@ int zigma_x_proj_fwd(const zigma_xproj_params_t *p, void *stream);
  * the scan) is written once and not read back.  bf16 throughout, fp32 accumulation; u is rounded to bf16 BEFORE the
  * projection, as in the reference.  x: (batch, seqlen, dim) channel-contiguous rows; conv_weight: (dim, 4) contiguous;
  * conv_bias: (dim); w: (n, dim) rows; u: (batch, seqlen, dim) in scan order; out: (batch * seqlen, n) rows.
- * Limits: width 4, bias required, seqlen % 32 == 0, batch * seqlen % 256 == 0, dim % 64 == 0, n <= 96, 16-byte aligned rows.
+ * Limits: width 4, bias required, seqlen % 32 == 0, batch * seqlen % 256 == 0, dim % 64 == 0, n <= 96 and n % 8 == 0, 16-byte
+ * aligned rows (x, u, w, out).
  * flags: 0; probes: 1 = three LDS stages, 2 = eight-wave workgroups, 4 / 8 = phases skipped (results wrong).
  * ------------------------------------------------------------------------------------------ */
 typedef struct zigma_conv_xproj_params {
@@ -401,6 +402,14 @@ typedef struct zigma_conv_xproj_params {
     const void *x, *conv_weight, *conv_bias, *w;
     void *u, *out;
     const int32_t *x_row_index;   /* or NULL */
+    /* optional third product (delta != NULL), the dt_proj of zigma_dt_proj_softplus_fwd on this workgroup's own x_dbl rows:
+     *   delta[m, d] = act( sum_{r<dt_rank} out[m, r] * dt_w[d, r] + dt_bias[d] ),  act = softplus iff dt_softplus
+     * dt_w: (dim, dt_rank) bf16 rows; dt_bias: float32 (dim) or NULL; delta: (batch * seqlen, dim) bf16 rows.
+     * dt_rank % 8 == 0, 8 <= dt_rank <= 48. */
+    int32_t dt_rank, dt_softplus;
+    int64_t dt_w_row_stride, delta_row_stride;
+    const void *dt_w, *dt_bias;
+    void *delta;
 } zigma_conv_xproj_params_t;
 
 int zigma_conv_x_proj_fwd(const zigma_conv_xproj_params_t *p, void *stream);

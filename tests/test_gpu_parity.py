@@ -537,6 +537,19 @@ def test_conv_x_proj_kernel_vs_oracle(Bsz, L, Di, Nn, order, flags):
     differ = (u_sep != u)
     assert differ.float().mean().item() < 0.02
     assert torch.allclose(u_sep.float(), u.float(), rtol=1e-2, atol=1e-3)
+    # third product of the same launch: delta = softplus(x_dbl[:, :R] @ W_dt^T + b) — u and x_dbl unchanged bit for bit, delta vs
+    # float64 on the kernel's own (bf16) x_dbl, and bit-identical to the stand-alone dt_proj kernel on that x_dbl
+    from zigma_amd.selective_scan_interface import dt_proj_softplus
+    R = 8 if Nn == 40 else 40
+    dw = zo.bf16_round((rng.standard_normal((Di, R)) * R ** -0.5).astype(np.float32))
+    db = (rng.random(Di) * 0.5).astype(np.float32)
+    for sp in (True, False):
+        u3, xd3, delta = conv_x_proj(x_half, cwt, cbt, wt, pt, _flags=flags, dt_weight=T(dw, torch.bfloat16), dt_bias=T(db), dt_softplus=sp)
+        assert _lib.last_kernel() == "conv_x_proj_dt_mfma" and torch.equal(u3, u) and torch.equal(xd3, x_dbl)
+        pre_d = N(x_dbl)[..., :R].astype(np.float64) @ dw.astype(np.float64).T + db
+        d_ref = zo.bf16_round((np.where(pre_d > 20, pre_d, np.log1p(np.exp(np.minimum(pre_d, 20)))) if sp else pre_d).astype(np.float32))
+        assert rel_err(N(delta), d_ref) < 3e-3 and np.allclose(N(delta), d_ref, rtol=2e-2, atol=2e-2)
+        assert torch.equal(delta, dt_proj_softplus(x_dbl, R, T(dw, torch.bfloat16), T(db), sp))
 
 
 @pytest.mark.parametrize("Bsz,L,H,NC", [(2, 100, 8, 77), (1, 64, 3, 128), (3, 17, 8, 5), (2, 256, 8, 81)])

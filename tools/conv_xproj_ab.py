@@ -3,7 +3,7 @@ against the two separate kernels (conv_tok, x_proj_mfma), interleaved rounds in 
 import json, os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from zigma_amd.causal_conv1d_interface import causal_conv1d_raw
-from zigma_amd.selective_scan_interface import conv_x_proj, x_proj
+from zigma_amd.selective_scan_interface import conv_x_proj, x_proj, dt_proj_softplus
 dev, dt = "cuda", torch.bfloat16
 B, L, Di, n = int(os.environ.get("B", 64)), int(os.environ.get("L", 1024)), 1280, 72
 torch.manual_seed(0)
@@ -11,6 +11,8 @@ xz = torch.randn(B, L, 2 * Di, device=dev, dtype=dt)
 cw = (0.5 * torch.randn(Di, 4, device=dev)).to(dt); cb = (0.5 * torch.randn(Di, device=dev)).to(dt)
 w = (Di ** -0.5 * torch.randn(n, Di, device=dev)).to(dt)
 perm = torch.randperm(L, device=dev).to(torch.int32)
+R = 40
+dw = (R ** -0.5 * torch.randn(Di, R, device=dev)).to(dt); db = torch.rand(Di, device=dev)
 x_half = xz[:, :, :Di]
 u_sep = torch.empty(B, L, Di, device=dev, dtype=dt)
 
@@ -20,8 +22,20 @@ def separate():
     return u_sep, x_proj(u_sep, w)
 
 
+def separate_dt():
+    u, xd = separate()
+    return u, xd, dt_proj_softplus(xd, R, dw, db, True)
+
+
+def fused_then_dt():
+    u, xd = conv_x_proj(x_half, cw, cb, w, perm)
+    return u, xd, dt_proj_softplus(xd, R, dw, db, True)
+
+
 F = lambda fl: (lambda: conv_x_proj(x_half, cw, cb, w, perm, _flags=fl))
-variants = {"separate": separate, "fused": F(0), "fused_3stage": F(1), "fused_8w": F(2), "fused_8w_3stage": F(3),
+variants = {"separate": separate, "separate_dt": separate_dt, "fused_then_dt": fused_then_dt,
+            "fused_dt": lambda: conv_x_proj(x_half, cw, cb, w, perm, dt_weight=dw, dt_bias=db),
+            "fused_dt_8w": lambda: conv_x_proj(x_half, cw, cb, w, perm, _flags=2, dt_weight=dw, dt_bias=db), "fused": F(0), "fused_3stage": F(1), "fused_8w": F(2), "fused_8w_3stage": F(3),
             "probe_nostore": F(4), "probe_noconv": F(8), "probe_neither": F(12)}
 outs = {k: f() for k, f in variants.items()}
 torch.cuda.synchronize()

@@ -117,7 +117,9 @@ class XProjParams(C.Structure):
 class ConvXProjParams(C.Structure):
     _fields_ = ([(n, i32) for n in ("batch", "seqlen", "dim", "n", "dtype", "flags")]
                 + [(n, i64) for n in ("x_batch_stride", "x_l_stride", "u_batch_stride", "u_l_stride", "w_row_stride", "out_row_stride")]
-                + [(n, vp) for n in ("x", "conv_weight", "conv_bias", "w", "u", "out", "x_row_index")])
+                + [(n, vp) for n in ("x", "conv_weight", "conv_bias", "w", "u", "out", "x_row_index")]
+                + [("dt_rank", i32), ("dt_softplus", i32), ("dt_w_row_stride", i64), ("delta_row_stride", i64)]
+                + [(n, vp) for n in ("dt_w", "dt_bias", "delta")])
 
 
 class LinearParams(C.Structure):

@@ -80,7 +80,7 @@ __device__ __forceinline__ void wait_vm_n(int n) {
     }
 }
 
-template <int NST, int NW>
+template <int NST, int NW, bool DT>
 __global__ __launch_bounds__(64 * NW) void conv_x_proj_kernel(const zigma_conv_xproj_params_t p) {
     constexpr int kCxWaves = NW, kCxWOff = cx_w_off(NW), kCxCOff = cx_c_off(NW), kCxStage = cx_stage(NW), NWI = (12 + NW - 1) / NW;
     __shared__ __attribute__((aligned(1024))) unsigned char smem[NST * kCxStage];
@@ -220,7 +220,7 @@ __global__ __launch_bounds__(64 * NW) void conv_x_proj_kernel(const zigma_conv_x
             const bf16x8 a = __builtin_bit_cast(bf16x8, u8);
 #pragma unroll
             for (int nb = 0; nb < 3; ++nb)
-                acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, __builtin_bit_cast(bf16x8, k.Bf[nb]), acc[nb], 0, 0, 0);
+                acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, k.Bf[nb]), a, acc[nb], 0, 0, 0);
         }
         // u of this stage (32 positions x 64 channels per wave) leaves as FULL 128-byte lines: a lane holds 16-byte pieces of its own
         // row only (two lanes = 32 contiguous bytes per store instruction and row — measured: the partial-line stores cost more than
@@ -238,15 +238,85 @@ __global__ __launch_bounds__(64 * NW) void conv_x_proj_kernel(const zigma_conv_x
             for (int i = 0; i < 4; ++i) *reinterpret_cast<u32x4 *>(ust + static_cast<int64_t>(i * 8) * u_pitch + st * (kCxBK * 2)) = t[i];
         }
     }
-    // C/D layout: column = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
-    uint16_t *ow = reinterpret_cast<uint16_t *>(p.out);
+    // ---- x_dbl tile of this wave.  The products were taken transposed (W_x rows as the MFMA A operand): D[n][position], a lane holds
+    // position j and the outputs n = nb * 32 + (r & 3) + 8 (r >> 2) + 4 kh — 4 consecutive n per register group, one 8-byte piece.
+    // The tile goes through LDS (32 rows x 208 B, wave-private; the stage ring is free behind the barrier) and leaves as 16-byte
+    // row pieces; with DT it is also the A operand of the dt_proj product below.
+    __builtin_amdgcn_s_barrier();
+    constexpr int kPitch = 208;
+    const unsigned tile = smem_lds + wave * 8192;
 #pragma unroll
-    for (int nb = 0; nb < 3; ++nb) {
-        const int n = nb * 32 + j;
+    for (int nb = 0; nb < 3; ++nb)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int64_t m = m0 + (r & 3) + 8 * (r >> 2) + 4 * kh;
-            if (n < p.n) ow[m * p.out_row_stride + n] = from_float<BF16>(acc[nb][r]);
+        for (int q = 0; q < 4; ++q) {
+            typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+            const u32x2 pk = {pack_bf2(acc[nb][q * 4], acc[nb][q * 4 + 1]), pack_bf2(acc[nb][q * 4 + 2], acc[nb][q * 4 + 3])};
+            asm volatile("ds_write_b64 %0, %1" ::"v"(tile + j * kPitch + nb * 64 + q * 16 + kh * 8), "v"(pk) : "memory");
+        }
+    {
+        const int pc = lane & 15, r4 = lane >> 4;                     // 4 rows x 16 pieces per instruction
+        unsigned char *ob = reinterpret_cast<unsigned char *>(p.out) + (m0 + r4) * p.out_row_stride * 2 + pc * 16;
+        u32x4 t[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) lds_rd(t[i], tile + (i * 4 + r4) * kPitch + pc * 16);
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(t[0]), "+v"(t[1]), "+v"(t[2]), "+v"(t[3]), "+v"(t[4]), "+v"(t[5]), "+v"(t[6]), "+v"(t[7]));
+        if (pc * 8 < p.n) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) *reinterpret_cast<u32x4 *>(ob + static_cast<int64_t>(i * 4) * p.out_row_stride * 2) = t[i];
+        }
+    }
+    if (!DT) return;
+    // ---- delta = softplus(x_dbl[:, :dt_rank] @ W_dt^T + bias) for these 32 positions, all d_inner channels (dt_proj.hip's wave tile:
+    // even / odd channel B fragments, a lane ends up with channels 2j, 2j+1 of a position: packed 4-byte stores, 128 B per row) ------
+    {
+        const int R = p.dt_rank;
+        bf16x8 af[3];
+#pragma unroll
+        for (int s = 0; s < 3; ++s) {
+            const int k0 = s * 16 + kh * 8;
+            u32x4 v;
+            lds_rd(v, tile + j * kPitch + (k0 < R ? k0 : 0) * 2);
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(v));
+            af[s] = __builtin_bit_cast(bf16x8, k0 < R ? v : u32x4{0, 0, 0, 0});
+        }
+        const uint16_t *ww = reinterpret_cast<const uint16_t *>(p.dt_w);
+        const float *bias = reinterpret_cast<const float *>(p.dt_bias);
+        auto wfrags = [&](int d0, bf16x8 (&be)[3], bf16x8 (&bo)[3], float &b_e, float &b_o) {
+            const uint16_t *we = ww + static_cast<int64_t>(d0 + 2 * j) * p.dt_w_row_stride;
+            const uint16_t *wo = we + p.dt_w_row_stride;
+#pragma unroll
+            for (int s = 0; s < 3; ++s) {
+                const int k0 = s * 16 + kh * 8;
+                const uint4 ve = *reinterpret_cast<const uint4 *>(we + (k0 < R ? k0 : 0)), vo = *reinterpret_cast<const uint4 *>(wo + (k0 < R ? k0 : 0));
+                be[s] = __builtin_bit_cast(bf16x8, k0 < R ? ve : make_uint4(0, 0, 0, 0));
+                bo[s] = __builtin_bit_cast(bf16x8, k0 < R ? vo : make_uint4(0, 0, 0, 0));
+            }
+            b_e = bias ? bias[d0 + 2 * j] : 0.f;
+            b_o = bias ? bias[d0 + 2 * j + 1] : 0.f;
+        };
+        bf16x8 be[3], bo[3], be_n[3], bo_n[3];
+        float b_e, b_o, b_en = 0.f, b_on = 0.f;
+        wfrags(0, be, bo, b_e, b_o);
+        uint16_t *orow = reinterpret_cast<uint16_t *>(p.delta) + (m0 + 4 * kh) * p.delta_row_stride + 2 * j;
+#pragma unroll 1
+        for (int d0 = 0; d0 < p.dim; d0 += 64) {
+            if (d0 + 64 < p.dim) wfrags(d0 + 64, be_n, bo_n, b_en, b_on);   // requested before this block's softplus / stores
+            f32x16 ce = {}, co = {};
+#pragma unroll
+            for (int s = 0; s < 3; ++s) {
+                ce = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[s], be[s], ce, 0, 0, 0);
+                co = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[s], bo[s], co, 0, 0, 0);
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int dm = (r & 3) + 8 * (r >> 2);
+                float ve = ce[r] + b_e, vo = co[r] + b_o;
+                if (p.dt_softplus) { ve = softplus20_r16(ve); vo = softplus20_r16(vo); }
+                *reinterpret_cast<uint32_t *>(orow + dm * p.delta_row_stride + d0) = pack_bf2(ve, vo);
+            }
+#pragma unroll
+            for (int s = 0; s < 3; ++s) { be[s] = be_n[s]; bo[s] = bo_n[s]; }
+            b_e = b_en; b_o = b_on;
         }
     }
 }
@@ -264,7 +334,15 @@ extern "C" int zigma_conv_x_proj_fwd(const zigma_conv_xproj_params_t *pp, void *
     if (p.batch == 0 || p.seqlen == 0) return ZIGMA_OK;
     if (!p.x || !p.conv_weight || !p.conv_bias || !p.w || !p.u || !p.out) return ZIGMA_ERR_NULL;
     if (p.dtype != ZIGMA_BF16) return ZIGMA_ERR_DTYPE;
-    if (p.n > 96 || p.dim % kCxBK != 0 || p.seqlen % kCxTok != 0) return ZIGMA_ERR_SHAPE;
+    if (p.n > 96 || p.n % 8 != 0 || p.dim % kCxBK != 0 || p.seqlen % kCxTok != 0) return ZIGMA_ERR_SHAPE;
+    if (p.delta) {                       // optional third product: delta = softplus(x_dbl[:, :dt_rank] @ dt_w^T + dt_bias)
+        if (!p.dt_w) return ZIGMA_ERR_NULL;
+        if (p.dt_rank < 8 || p.dt_rank > 48 || p.dt_rank % 8 != 0 || p.dt_rank > p.n) return ZIGMA_ERR_SHAPE;
+        if (p.dt_w_row_stride % 8 != 0 || p.delta_row_stride % 2 != 0 || reinterpret_cast<uintptr_t>(p.dt_w) % 16 != 0 ||
+            reinterpret_cast<uintptr_t>(p.delta) % 4 != 0)
+            return ZIGMA_ERR_STRIDE;
+    }
+    if (p.out_row_stride % 8 != 0 || reinterpret_cast<uintptr_t>(p.out) % 16 != 0) return ZIGMA_ERR_STRIDE;
     const int64_t m = static_cast<int64_t>(p.batch) * p.seqlen;
     if (m % (kCxTok * 8) != 0) return ZIGMA_ERR_SHAPE;       // (either workgroup size)
     auto al16 = [](const void *q) { return reinterpret_cast<uintptr_t>(q) % 16 == 0; };
@@ -276,15 +354,18 @@ extern "C" int zigma_conv_x_proj_fwd(const zigma_conv_xproj_params_t *pp, void *
     // while the other waits for its loads (measured 72 us; 8 waves in lockstep 75 us; a third stage does not pay, the second
     // workgroup does its job).  flags: 1 = three stages, 2 = eight-wave workgroups; probes (wrong results): 4 = no u stores,
     // 8 = no conv arithmetic.
+    const bool dt = p.delta != nullptr;
+#define ZIGMA_CX(S_, W_)                                                                                        \
+    if (dt) hipLaunchKernelGGL((conv_x_proj_kernel<S_, W_, true>), grid, block, 0, stream, p);                  \
+    else hipLaunchKernelGGL((conv_x_proj_kernel<S_, W_, false>), grid, block, 0, stream, p);
     if (p.flags & 2) {
         const dim3 grid(static_cast<unsigned>(m / (kCxTok * 8))), block(64 * 8);
-        if (p.flags & 1) hipLaunchKernelGGL((conv_x_proj_kernel<3, 8>), grid, block, 0, stream, p);
-        else hipLaunchKernelGGL((conv_x_proj_kernel<2, 8>), grid, block, 0, stream, p);
+        if (p.flags & 1) { ZIGMA_CX(3, 8) } else { ZIGMA_CX(2, 8) }
     } else {
         const dim3 grid(static_cast<unsigned>(m / (kCxTok * 4))), block(64 * 4);
-        if (p.flags & 1) hipLaunchKernelGGL((conv_x_proj_kernel<3, 4>), grid, block, 0, stream, p);
-        else hipLaunchKernelGGL((conv_x_proj_kernel<2, 4>), grid, block, 0, stream, p);
+        if (p.flags & 1) { ZIGMA_CX(3, 4) } else { ZIGMA_CX(2, 4) }
     }
-    set_last_kernel("conv_x_proj_mfma");
+#undef ZIGMA_CX
+    set_last_kernel(dt ? "conv_x_proj_dt_mfma" : "conv_x_proj_mfma");
     return check_launch();
 }
