@@ -16,9 +16,13 @@
 //   lie in the (d_inner, 4) bf16 weight, SiLU, pack: the 8 bf16 are the A fragment of v_mfma_f32_32x32x16_bf16 against the W_x
 //   slab (32 x 96 fp32 accumulator per wave, rows beyond n are never stored); u leaves once per stage as full 128-byte lines,
 //   transposed through the wave's own (consumed) input rows.
+//   The products are taken transposed (W_x rows as the MFMA A operand, D[n][position]) so that a lane holds 4 consecutive n of its
+//   position: the x_dbl tile goes through LDS as 8-byte pieces and leaves as 16-byte row pieces.  Optionally (delta != NULL) each
+//   wave then runs dt_proj.hip's wave tile on that LDS tile for all d_inner channels: delta = softplus(x_dbl[:, :R] W_dt^T + b) —
+//   bit-identical to the stand-alone kernel and NOT faster than it (138.7 vs 71.3 + 64.4 us), so the host leaves it off.
 // Measured at the headline shape (B=64, L=1024, d_inner=1280, n=72): 72 us against 131 us for conv_tok + x_proj_mfma
 // (tools/conv_xproj_ab.py); loads + MFMA alone 35 us, + conv 64 us, + stores 64 us (probe flags).
-// bf16 only; width 4; bias required; seqlen % 32 == 0; d_inner % 64 == 0; n <= 96.
+// bf16 only; width 4; bias required; seqlen % 32 == 0; d_inner % 64 == 0; n <= 96, n % 8 == 0.
 #include "zigma_common.h"
 
 namespace zigma {
