@@ -696,6 +696,37 @@ def test_linear_kernel_vs_float64(M, K, N, bias, act, monkeypatch):
         assert torch.equal(wide[:, 64:64 + N], y) and float(wide[:, :64].abs().max()) == 0 and float(wide[:, 64 + N:].abs().max()) == 0
 
 
+def test_backward_batch_beyond_the_grid_limit_runs_in_slices():
+    """batch > 65535 through the BACKWARD wrappers (scan and conv): slices, parameter gradients summed; compared with the same
+    rows run as two ordinary batches."""
+    from zigma_amd.causal_conv1d_interface import conv_bwd_tok
+    from zigma_amd.selective_scan_interface import scan_bwd_tok
+    g = torch.Generator(device="cpu").manual_seed(5)
+    Bsz, L, Dm, Nst = 65535 + 9, 16, 64, 16
+    bf = torch.bfloat16
+    mk = lambda *s, sc=1.0, dt=bf: (torch.randn(*s, generator=g) * sc).to(DEV, dt)
+    u, z, dout, out = mk(Bsz, L, Dm), mk(Bsz, L, Dm), mk(Bsz, L, Dm), mk(Bsz, L, Dm)
+    delta = (torch.rand(Bsz, L, Dm, generator=g) * 0.5).to(DEV, bf)
+    Bm, Cm = mk(Bsz, L, Nst), mk(Bsz, L, Nst)
+    A = (-torch.exp(torch.randn(Dm, Nst, generator=g) * 0.5)).to(DEV)
+    D, db = mk(Dm, dt=torch.float32), (torch.rand(Dm, generator=g) * 0.5).to(DEV)
+    full = scan_bwd_tok(u, delta, A, Bm, Cm, D, z, db, dout, out, True)
+    h = Bsz // 2
+    p1 = scan_bwd_tok(u[:h], delta[:h], A, Bm[:h], Cm[:h], D, z[:h], db, dout[:h], out[:h], True)
+    p2 = scan_bwd_tok(u[h:], delta[h:], A, Bm[h:], Cm[h:], D, z[h:], db, dout[h:], out[h:], True)
+    for i in (0, 1, 3, 4, 6):                                   # per-sample outputs: identical rows
+        assert torch.equal(full[i][:h], p1[i]) and torch.equal(full[i][h:], p2[i])
+    for i in (2, 5, 7):                                         # parameter gradients: sums over the batch (fp32, other order)
+        assert rel_err(N(full[i]), N(p1[i] + p2[i])) < 1e-5
+    w, cb = mk(Dm, 4, sc=0.5), mk(Dm, sc=0.1)
+    perm = torch.randperm(L, generator=g).to(DEV, torch.int32)
+    fx, fw, fb = conv_bwd_tok(u, w, cb, dout, True, perm)
+    x1, w1, b1 = conv_bwd_tok(u[:h], w, cb, dout[:h], True, perm)
+    x2, w2, b2 = conv_bwd_tok(u[h:], w, cb, dout[h:], True, perm)
+    assert torch.equal(fx[:h], x1) and torch.equal(fx[h:], x2)
+    assert rel_err(N(fw), N(w1 + w2)) < 1e-5 and rel_err(N(fb), N(b1 + b2)) < 1e-5
+
+
 def test_batch_beyond_the_grid_limit_runs_in_slices():
     """batch > 65535 (the differentiable video temporal path reshapes to (batch * K, T, C)): conv and scan forward slice the
     batch instead of failing the launch; compared with the same rows run as a small batch."""

@@ -73,6 +73,14 @@ def conv_bwd_tok(x, weight, bias, dout, silu, x_row_index=None, dx=None):
         dx = torch.empty(Bsz, L, Dm, device=x.device, dtype=x.dtype)
     elif dx.shape != x.shape or dx.stride(2) != 1 or dx.dtype != x.dtype:
         raise RuntimeError("dx must be (batch, seqlen, dim) with channel stride 1 and the dtype of x")
+    if Bsz > 65535:          # one launch rides the batch in a 16-bit grid dimension: slices, parameter gradients summed
+        dw = db = None
+        for a in range(0, Bsz, 65535):
+            b = min(a + 65535, Bsz)
+            _, dwi, dbi = conv_bwd_tok(x[a:b], weight, bias, dout[a:b], silu, x_row_index, dx=dx[a:b])
+            dw = dwi if dw is None else dw + dwi
+            db = dbi if db is None or dbi is None else db + dbi
+        return dx, dw, db
     dw = torch.zeros(Dm, w.shape[1], device=x.device, dtype=torch.float32)
     db = torch.zeros(Dm, device=x.device, dtype=torch.float32) if bias is not None else None
     P = _lib.ConvBwdParams()

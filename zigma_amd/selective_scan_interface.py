@@ -292,6 +292,9 @@ def dt_proj_softplus(x_dbl, dt_rank, weight, bias=None, softplus=True):
     return out.reshape(*lead, n)
 
 
+BWD_MAX_BATCH = 65535        # batch limit of one zigma_selective_scan_bwd / zigma_causal_conv1d_bwd launch (grid dimension)
+
+
 def scan_bwd_tok(u, delta, A, B, C, D, z, delta_bias, dout, out, delta_softplus, *, dB=None, dC=None, dz=None,
                  z_row_index=None, out_row_index=None, checkpoints=None):
     """Backward of the token-major selective scan (zigma_selective_scan_bwd; reference selective_scan_cuda.bwd,
@@ -308,6 +311,28 @@ def scan_bwd_tok(u, delta, A, B, C, D, z, delta_bias, dout, out, delta_softplus,
     dev = _lib.require_device(u, delta, A, B, C, D, z, delta_bias, dout, out)
     Bsz, L, Dm = u.shape
     N = A.shape[1]
+    if Bsz > BWD_MAX_BATCH:
+        # the kernel rides the batch in a 16-bit grid dimension: larger batches (the differentiable video temporal path reshapes to
+        # batch * tokens-per-frame rows) go in slices; per-sample outputs land in views of one allocation, the parameter gradients
+        # (dA, dD, ddelta_bias) are summed over the slices
+        du, ddelta = torch.empty_like(u, memory_format=torch.contiguous_format), torch.empty_like(u, memory_format=torch.contiguous_format)
+        if z is not None and dz is None:
+            dz = torch.empty_like(u, memory_format=torch.contiguous_format)
+        f32 = dict(device=u.device, dtype=torch.float32)
+        dB = torch.empty(Bsz, L, N, **f32) if dB is None else dB
+        dC = torch.empty(Bsz, L, N, **f32) if dC is None else dC
+        dA = dD = dbias = None
+        sl = lambda t, a, b: None if t is None else t[a:b]
+        for a in range(0, Bsz, BWD_MAX_BATCH):
+            b = min(a + BWD_MAX_BATCH, Bsz)
+            r = scan_bwd_tok(u[a:b], delta[a:b], A, B[a:b], C[a:b], D, sl(z, a, b), delta_bias, dout[a:b], sl(out, a, b), delta_softplus,
+                             dB=dB[a:b], dC=dC[a:b], dz=sl(dz, a, b), z_row_index=z_row_index, out_row_index=out_row_index,
+                             checkpoints=None if checkpoints is None else checkpoints[a:b])
+            du[a:b].copy_(r[0]); ddelta[a:b].copy_(r[1])
+            dA = r[2] if dA is None else dA + r[2]
+            dD = r[5] if dD is None or r[5] is None else dD + r[5]
+            dbias = r[7] if dbias is None or r[7] is None else dbias + r[7]
+        return du, ddelta, dA, dB, dC, dD, dz, dbias
     for t, nm in ((u, "u"), (delta, "delta"), (z, "z"), (out, "out"), (dout, "dout")):
         if t is not None and (t.shape != (Bsz, L, Dm) or t.stride(2) != 1 or t.dtype != u.dtype):
             raise RuntimeError(f"{nm} must be (batch, seqlen, dim) with channel stride 1 and the dtype of u")
