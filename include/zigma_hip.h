@@ -380,6 +380,29 @@ typedef struct zigma_xproj_params {
 int zigma_x_proj_fwd(const zigma_xproj_params_t *p, void *stream);
 
 /* ------------------------------------------------------------------------------------------
+ * q_attn: the query projection AND the attention core of CrossAttention.forward over a short context in one kernel:
+ *   q = x @ w^T (bf16);   out[:, h*64:(h+1)*64] = softmax(scale * q_h k_h^T) v_h            per sample and head
+ * Replaces to_q + scaled_dot_product_attention of the reference (model_zigma.py:104-127, 8 heads x 64, 77 text tokens, no
+ * mask); q never reaches memory.  x: (batch * seqlen, k_dim) rows; w: (heads * 64, k_dim) = to_q.weight; k: (batch, n_ctx,
+ * heads * 64) = to_k(text); vt: (batch, heads * 64, vt_keys) = to_v(text) TRANSPOSED per sample, zero beyond n_ctx;
+ * out: (batch * seqlen, heads * 64).  Limits: bf16, head_dim 64, heads * 64 % 256 == 0, k_dim % 64 == 0, seqlen % 256 == 0,
+ * n_ctx <= 80 <= vt_keys <= 96, vt_keys % 16 == 0, k / vt rows 16-byte aligned.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct zigma_qattn_params {
+    int32_t batch, seqlen, n_ctx, heads, head_dim, k_dim;
+    int32_t vt_keys;
+    int32_t dtype;           /* ZIGMA_BF16 */
+    int32_t flags;           /* reserved, must be 0 */
+    float scale;
+    int64_t x_row_stride, w_row_stride, o_row_stride;
+    int64_t k_batch_stride, k_row_stride, vt_batch_stride, vt_row_stride;
+    const void *x, *w, *k, *vt;
+    void *out;
+} zigma_qattn_params_t;
+
+int zigma_q_attn_fwd(const zigma_qattn_params_t *p, void *stream);
+
+/* ------------------------------------------------------------------------------------------
  * conv_x_proj: the depthwise causal conv1d (+ bias, SiLU) over the reordered sequence AND x_proj of its result in one pass:
  *   u[b, k, c]   = silu(conv_bias[c] + sum_{w<4} conv_weight[c, w] * x[b, x_row_index[k - 3 + w], c])     (x[<0] = 0)
  *   out[b*L + k, n] = sum_c u[b, k, c] * w[n, c]

@@ -500,6 +500,38 @@ def test_x_proj_kernel_vs_oracle(M, K, Nn):
     assert rel_err(N(out), ref) < 3e-3 and np.allclose(N(out), ref, rtol=2e-2, atol=2e-2)
 
 
+@pytest.mark.parametrize("Bsz,L,E,H,NC", [(1, 256, 64, 4, 77), (2, 512, 640, 8, 77), (16, 1024, 640, 8, 77), (1, 256, 128, 4, 5), (3, 256, 192, 4, 80),
+                                          (2, 256, 64, 8, 40)])
+def test_q_attn_kernel_vs_float64(Bsz, L, E, H, NC):
+    """to_q + attention core in one kernel (zigma_q_attn_fwd) vs float64 numpy on the same bf16 operands with the reference's
+    rounding points (q rounded to bf16 before the scores; P rounded to bf16 before the second product), and against the two
+    separate HIP kernels (projection, then cross_attn)."""
+    from zigma_amd import _lib
+    from zigma_amd.attention import cross_attn, q_attn, q_attn_eligible, transpose_v
+    rng = np.random.default_rng(L + E + NC)
+    C = H * 64
+    x = zo.bf16_round(rng.standard_normal((Bsz, L, E)).astype(np.float32))
+    wq = zo.bf16_round((rng.standard_normal((C, E)) * E ** -0.5).astype(np.float32))
+    kv = zo.bf16_round(rng.standard_normal((Bsz, NC, 2, C)).astype(np.float32))
+    xt, wt, kvt = T(x, torch.bfloat16), T(wq, torch.bfloat16), T(kv, torch.bfloat16)
+    k, v = kvt[:, :, 0], kvt[:, :, 1]
+    assert q_attn_eligible(xt, wt, k, H) == (Bsz * L >= 16384)
+    out = q_attn(xt, wt, k, transpose_v(v), H)
+    assert _lib.last_kernel() == "q_attn_256x256" and out.shape == (Bsz, L, C)
+    q = zo.bf16_round((x.astype(np.float64) @ wq.astype(np.float64).T).astype(np.float32)).astype(np.float64)
+    qh = q.reshape(Bsz, L, H, 64).transpose(0, 2, 1, 3)
+    kh = kv[:, :, 0].reshape(Bsz, NC, H, 64).transpose(0, 2, 1, 3).astype(np.float64)
+    vh = kv[:, :, 1].reshape(Bsz, NC, H, 64).transpose(0, 2, 1, 3).astype(np.float64)
+    s = qh @ kh.transpose(0, 1, 3, 2) * 0.125
+    pr = np.exp(s - s.max(-1, keepdims=True))
+    ref = (pr @ vh) / pr.sum(-1, keepdims=True)
+    ref = ref.transpose(0, 2, 1, 3).reshape(Bsz, L, C)
+    assert rel_err(N(out), ref) < 8e-3                       # (P rounded to bf16 before the second MFMA, like cross_attn)
+    qt = torch.nn.functional.linear(xt, wt)
+    two = cross_attn(qt, k, v, H)
+    assert rel_err(N(out), N(two)) < 8e-3
+
+
 @pytest.mark.parametrize("Bsz,L,Di,Nn,order,flags", [(2, 128, 64, 72, "id", 0), (1, 256, 192, 40, "rand", 0), (1, 256, 192, 40, "rand", 3),
                                                    (16, 1024, 1280, 72, "rand", 0), (64, 256, 128, 96, "none", 1),
                                                    (4, 4096, 640, 72, "rev", 2), (8, 32, 64, 72, "rand", 0)])

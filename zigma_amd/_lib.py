@@ -109,6 +109,13 @@ class XAttnParams(C.Structure):
                 + [(n, vp) for n in ("q", "k", "v", "out")])
 
 
+class QAttnParams(C.Structure):
+    _fields_ = ([(n, i32) for n in ("batch", "seqlen", "n_ctx", "heads", "head_dim", "k_dim", "vt_keys", "dtype", "flags")] + [("scale", f32)]
+                + [(n, i64) for n in ("x_row_stride", "w_row_stride", "o_row_stride", "k_batch_stride", "k_row_stride", "vt_batch_stride",
+                                      "vt_row_stride")]
+                + [(n, vp) for n in ("x", "w", "k", "vt", "out")])
+
+
 class XProjParams(C.Structure):
     _fields_ = ([("m", i64), ("n", i32), ("k", i32), ("dtype", i32), ("flags", i32)]
                 + [(n, i64) for n in ("x_row_stride", "w_row_stride", "out_row_stride")] + [(n, vp) for n in ("x", "w", "out")])
@@ -127,7 +134,7 @@ class LinearParams(C.Structure):
                 + [(n, i64) for n in ("x_row_stride", "w_row_stride", "out_row_stride")] + [(n, vp) for n in ("x", "w", "bias", "out")])
 
 
-EXPORTS = ("zigma_linear_fwd", "zigma_conv_x_proj_fwd", "zigma_selective_scan_fwd", "zigma_causal_conv1d_fwd", "zigma_add_norm_fwd", "zigma_dt_proj_softplus_fwd", "zigma_cross_attn_fwd", "zigma_x_proj_fwd", "zigma_selective_scan_bwd",
+EXPORTS = ("zigma_linear_fwd", "zigma_conv_x_proj_fwd", "zigma_q_attn_fwd", "zigma_selective_scan_fwd", "zigma_causal_conv1d_fwd", "zigma_add_norm_fwd", "zigma_dt_proj_softplus_fwd", "zigma_cross_attn_fwd", "zigma_x_proj_fwd", "zigma_selective_scan_bwd",
            "zigma_selective_scan_bwd_workspace_bytes", "zigma_causal_conv1d_bwd",
            "zigma_causal_conv1d_bwd_workspace_bytes", "zigma_add_norm_bwd", "zigma_add_norm_bwd_workspace_bytes",
            "zigma_strerror",
@@ -149,7 +156,7 @@ def lib():
                          ("zigma_add_norm_fwd", NormParams), ("zigma_dt_proj_softplus_fwd", DtProjParams),
                          ("zigma_selective_scan_bwd", ScanBwdParams), ("zigma_causal_conv1d_bwd", ConvBwdParams),
                          ("zigma_add_norm_bwd", NormBwdParams), ("zigma_cross_attn_fwd", XAttnParams), ("zigma_x_proj_fwd", XProjParams),
-                         ("zigma_linear_fwd", LinearParams), ("zigma_conv_x_proj_fwd", ConvXProjParams)):
+                         ("zigma_linear_fwd", LinearParams), ("zigma_conv_x_proj_fwd", ConvXProjParams), ("zigma_q_attn_fwd", QAttnParams)):
             fn = getattr(L, name)
             fn.argtypes = [C.POINTER(st), vp]
             fn.restype = C.c_int

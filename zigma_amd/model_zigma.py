@@ -28,7 +28,7 @@ import torch.nn.functional as F
 import torch.utils.checkpoint
 from torch import Tensor
 
-from .attention import cross_attn, cross_attn_eligible
+from .attention import USE_Q_ATTN, cross_attn, cross_attn_eligible, q_attn, q_attn_eligible, transpose_v
 from .layernorm import RMSNorm, block_norm, layer_norm_fn, rms_norm_fn
 from .linear import linear, linear_eligible
 from .mamba_simple import Mamba
@@ -118,8 +118,12 @@ class CrossAttention(nn.Module):
         projections of all layers into one GEMM since `text` is the same for every block."""
         Bsz, L, _ = x.shape
         H = self.heads
+        k, v = kv[:2] if kv is not None else (self.to_k(text), self.to_v(text))
+        if USE_Q_ATTN and not torch.is_grad_enabled() and q_attn_eligible(x, self.to_q.weight, k, H):
+            # HIP kernels: to_q AND the attention core in one pass (q stays in the accumulators), to_out on the MFMA projection kernel
+            vt = kv[2] if kv is not None and len(kv) > 2 else transpose_v(v)
+            return self.to_out[1](self._proj(q_attn(x, self.to_q.weight, k, vt, H, self.scale), self.to_out[0]))
         q = self._proj(x, self.to_q)
-        k, v = kv if kv is not None else (self.to_k(text), self.to_v(text))
         if not torch.is_grad_enabled() and cross_attn_eligible(q, k, v, H):
             # HIP kernels: attention core in one pass (K/V of the head in LDS), to_out on the MFMA projection kernel
             return self.to_out[1](self._proj(cross_attn(q, k, v, H, self.scale), self.to_out[0]))
@@ -590,6 +594,11 @@ class ZigMa(nn.Module):
             inner = blocks[0].msa.to_k.weight.shape[0]
             kv_all = F.linear(text, Wkv).view(text.shape[0], text.shape[1], n, 2, inner)
             kvs = [(kv_all[:, :, i, 0], kv_all[:, :, i, 1]) for i in range(n)]
+            if USE_Q_ATTN and not torch.is_grad_enabled() and text.shape[1] <= 80 and kv_all.dtype == torch.bfloat16 and kv_all.is_cuda:
+                # V^T of every layer in one copy (rows contiguous over the zero-padded keys): what the one-kernel to_q + attention reads
+                vt_all = torch.zeros(text.shape[0], n, inner, 96, device=kv_all.device, dtype=kv_all.dtype)
+                vt_all[:, :, :, :text.shape[1]] = kv_all[:, :, :, 1].permute(0, 2, 3, 1)
+                kvs = [kvs[i] + (vt_all[:, i],) for i in range(n)]
         return mods, kvs
 
     def ckpt_wrapper(self, module):
