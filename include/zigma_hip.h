@@ -27,8 +27,9 @@
 extern "C" {
 #endif
 
-#define ZIGMA_ABI_VERSION 3   /* 2: parameter blocks grew (row tables in the backward, checkpoints, reset_period)
-                               * 3: scan block: `info` out-field, ZIGMA_SCAN_Z_PREACTIVATED flag; zigma_linear_fwd */
+#define ZIGMA_ABI_VERSION 4   /* 2: parameter blocks grew (row tables in the backward, checkpoints, reset_period)
+                               * 3: scan block: `info` out-field, ZIGMA_SCAN_Z_PREACTIVATED flag; zigma_linear_fwd
+                               * 4: zigma_linear_params_t grew (gated residual epilogue); zigma_conv_x_proj_fwd, zigma_q_attn_fwd */
 
 /* zigma_scan_params_t.flags */
 #define ZIGMA_SCAN_Z_PREACTIVATED 2   /* z already holds silu(z) (the in_proj GEMM epilogue applied it): out_z = y * z */
@@ -457,6 +458,13 @@ typedef struct zigma_linear_params {
     const void *x, *w;
     const void *bias;        /* or NULL */
     void *out;
+    /* optional gated residual in the epilogue (ABI 4) — CrossAttention's `hidden + gate_msa * to_out(...)` (model_zigma.py:447-449):
+     *   out[m, :] = residual[m, :] + gate[m / rows_per_batch, :] * bf16(x @ w^T + bias)[m, :]
+     * residual: (m, n) bf16 rows of pitch res_row_stride; gate: (m / rows_per_batch, n) bf16 rows of pitch gate_batch_stride;
+     * rows_per_batch % 256 == 0.  residual == NULL: plain projection. */
+    const void *residual, *gate;
+    int64_t res_row_stride, gate_batch_stride;
+    int32_t rows_per_batch, pad2_;
 } zigma_linear_params_t;
 
 int zigma_linear_fwd(const zigma_linear_params_t *p, void *stream);

@@ -728,6 +728,33 @@ def test_linear_kernel_vs_float64(M, K, N, bias, act, monkeypatch):
         assert torch.equal(wide[:, 64:64 + N], y) and float(wide[:, :64].abs().max()) == 0 and float(wide[:, 64 + N:].abs().max()) == 0
 
 
+@pytest.mark.parametrize("Bsz,L,K,Nn,bias", [(2, 256, 512, 640, True), (3, 512, 128, 128, False), (16, 1024, 512, 640, True)])
+def test_linear_gated_residual_epilogue(Bsz, L, K, Nn, bias, monkeypatch):
+    """out = residual + gate[b] * bf16(x @ W^T + bias) in the projection kernel's epilogue (the block's gated branch add) vs the
+    same thing spelled out in float64 with the projection rounded to bf16 first."""
+    import zigma_amd.linear as zl
+    from zigma_amd import _lib
+    from zigma_amd.linear import gated_residual_eligible, linear
+    monkeypatch.setattr(zl, "LINEAR_POLICY", "all")
+    g = torch.Generator(device="cpu").manual_seed(L + Nn)
+    bf = torch.bfloat16
+    x = torch.randn(Bsz, L, K, generator=g).to(DEV, bf)
+    w = (torch.randn(Nn, K, generator=g) * K ** -0.5).to(DEV, bf)
+    b = (torch.randn(Nn, generator=g) * 0.5).to(DEV, bf) if bias else None
+    wide = torch.randn(Bsz, L, Nn + 64, generator=g).to(DEV, bf)
+    res = wide[:, :, 64:]                                                        # a column slice: row pitch != n
+    gate = torch.randn(Bsz, 3 * Nn, generator=g).to(DEV, bf)[:, Nn:2 * Nn]      # a chunk of the adaLN rows
+    assert gated_residual_eligible(x, res, gate)
+    out = linear(x, w, b, residual=res, gate=gate)
+    assert _lib.last_kernel() == "linear_tn_256x128" and out.shape == (Bsz, L, Nn)
+    proj = (x.double() @ w.double().T + (b.double() if bias else 0)).to(bf).double()
+    ref = res.double() + gate.double().unsqueeze(1) * proj
+    assert float((out.double() - ref).norm() / ref.norm()) < 2.5e-3 and torch.allclose(out.double(), ref, rtol=1.6e-2, atol=1.6e-2)
+    plain = linear(x, w, b)                                                      # and the fp32 fma of the kernel's own bf16 projection
+    exact = torch.addcmul(res.float(), gate.float().unsqueeze(1), plain.float()).to(bf)
+    assert (out != exact).float().mean().item() < 1e-3                           # (fma vs mul + add: ties in the last place)
+
+
 def test_backward_batch_beyond_the_grid_limit_runs_in_slices():
     """batch > 65535 through the BACKWARD wrappers (scan and conv): slices, parameter gradients summed; compared with the same
     rows run as two ordinary batches."""

@@ -17,6 +17,18 @@ Bv = xdbl[:, :, R:R + N].transpose(1, 2).unsqueeze(1); Cv = xdbl[:, :, R + N:].t
 outs = {}
 
 
+db = torch.rand(Di, device=dev)
+
+
+def run_sp(name):
+    """softplus(delta + bias) evaluated INSIDE the kernel's prologue (what a caller without the dt_proj kernel gets)"""
+    os.environ.pop("ZIGMA_SCAN_KERNEL", None)
+    y = outs.setdefault(name, torch.empty(B, L, Di, device=dev, dtype=dt))
+    scan_raw(u.transpose(1, 2), delta.transpose(1, 2), A, Bv, Cv, D, xz[:, :, Di:].transpose(1, 2), db, True,
+             out_z=y.transpose(1, 2), z_row_index=perm, out_row_index=perm, want_out=False)
+    return _lib.last_kernel()
+
+
 def run(name, env, zact=False):
     if env:
         os.environ["ZIGMA_SCAN_KERNEL"] = env
@@ -28,7 +40,9 @@ def run(name, env, zact=False):
     return _lib.last_kernel()
 
 
-variants = [("v1", "v1", False), ("v2", None, False), ("v2_zact", None, True)]
+variants = [("v1", "v1", False), ("v2", None, False), ("v2_zact", None, True), ("v2_softplus_inside", "SP", False)]
+_run = run
+run = lambda n, e, z=False: run_sp(n) if e == "SP" else _run(n, e, z)
 names = {n: run(n, e, z) for n, e, z in variants}
 torch.cuda.synchronize()
 times = {n: [] for n, _, _ in variants}

@@ -131,7 +131,8 @@ class ConvXProjParams(C.Structure):
 
 class LinearParams(C.Structure):
     _fields_ = ([("m", i64), ("n", i32), ("k", i32), ("dtype", i32), ("flags", i32), ("silu_from_col", i32), ("pad_", i32)]
-                + [(n, i64) for n in ("x_row_stride", "w_row_stride", "out_row_stride")] + [(n, vp) for n in ("x", "w", "bias", "out")])
+                + [(n, i64) for n in ("x_row_stride", "w_row_stride", "out_row_stride")] + [(n, vp) for n in ("x", "w", "bias", "out")]
+                + [("residual", vp), ("gate", vp), ("res_row_stride", i64), ("gate_batch_stride", i64), ("rows_per_batch", i32), ("pad2_", i32)])
 
 
 EXPORTS = ("zigma_linear_fwd", "zigma_conv_x_proj_fwd", "zigma_q_attn_fwd", "zigma_selective_scan_fwd", "zigma_causal_conv1d_fwd", "zigma_add_norm_fwd", "zigma_dt_proj_softplus_fwd", "zigma_cross_attn_fwd", "zigma_x_proj_fwd", "zigma_selective_scan_bwd",
@@ -170,7 +171,7 @@ def lib():
         L.zigma_strerror.restype = C.c_char_p
         L.zigma_abi_version.restype = C.c_int
         L.zigma_last_kernel.restype = C.c_char_p
-        if L.zigma_abi_version() != 3:
+        if L.zigma_abi_version() != 4:
             raise RuntimeError("zigma_amd: libzigma_hip.so ABI version mismatch")
         _lib = L
     return _lib

@@ -41,10 +41,13 @@ constexpr int kLinBM = 256, kLinBK = 64;
 // of LDS, 32 tokens x 64 features at a time: + bias (fp32, before the single rounding), SiLU on whole 32-feature blocks,
 // packed 8-byte writes (16-byte slot ^= (token >> 1) & 7: conflict-free), 16-byte reads; every global store instruction then
 // covers 8 tokens x 128 contiguous bytes.  `s_bias`: the bias vector staged in LDS as bf16 (or nullptr).
-template <int MB, int NB>
+// RES: out = residual + gate * bf16(value) (CrossAttention's `hidden + gate_msa * to_out(...)`, reference model_zigma.py:447-449; the
+// projection result is rounded to bf16 first, as the reference's bf16 tensor is): the residual rows are fetched with the store
+// pattern (16 bytes per lane, 8 tokens x 128 B per instruction), `gate8` = this lane's 8 gate values (bf16).
+template <int MB, int NB, bool RES = false>
 __device__ __forceinline__ void linear_epilogue(const f32x16 (&acc)[NB][MB], unsigned char *scr, const uint16_t *s_bias,
                                                 const rsrc_t o_rs, const int64_t o_pitch, const int n_wave0, const int silu_from_col,
-                                                const int lane) {
+                                                const int lane, const rsrc_t r_rs, const int64_t r_pitch, const uint4 gate8) {
     const int j = lane & 31, kh = lane >> 5;
     const int wr_off = j * 128 + kh * 8, wr_sw = (j >> 1) & 7;                               // this lane's row in the scratch tile
     const int rd_tok = lane >> 3, rd_slot = (lane & 7) ^ (rd_tok >> 1);                      // row = i * 8 + rd_tok: swizzle (row >> 1) & 7
@@ -98,6 +101,22 @@ __device__ __forceinline__ void linear_epilogue(const f32x16 (&acc)[NB][MB], uns
         for (int i = 0; i < 4; ++i)
             asm volatile("ds_read_b128 %0, %1" : "=v"(row[i]) : "v"(scr_lds + i * 1024 + rd_tok * 128 + ((rd_slot ^ ((i & 1) << 2)) << 4)));
         asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(row[0]), "+v"(row[1]), "+v"(row[2]), "+v"(row[3]));
+        if constexpr (RES) {
+            const unsigned rs_off = static_cast<unsigned>(rd_tok * r_pitch + (lane & 7) * 16);
+            u4 res[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) res[i] = __builtin_amdgcn_raw_buffer_load_b128(r_rs, rs_off, static_cast<int>((mb * 32 + i * 8) * r_pitch), 0);
+            const unsigned gq[4] = {gate8.x, gate8.y, gate8.z, gate8.w};
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float lo = __builtin_fmaf(__uint_as_float(gq[e] << 16), __uint_as_float(row[i][e] << 16), __uint_as_float(res[i][e] << 16));
+                    const float hi = __builtin_fmaf(__uint_as_float(gq[e] & 0xffff0000u), __uint_as_float(row[i][e] & 0xffff0000u),
+                                                    __uint_as_float(res[i][e] & 0xffff0000u));
+                    row[i][e] = static_cast<uint32_t>(from_float<BF16>(lo)) | (static_cast<uint32_t>(from_float<BF16>(hi)) << 16);
+                }
+        }
 #pragma unroll
         for (int i = 0; i < 4; ++i)
             __builtin_amdgcn_raw_buffer_store_b128(row[i], o_rs, st_off, static_cast<int>((mb * 32 + i * 8) * o_pitch), 0);
@@ -249,7 +268,7 @@ __device__ __forceinline__ void wait_vm(int n) {
 // was issued after the batch this k-step needs": the younger load batch (NST == 3) and, during the first NST - 1 k-steps
 // after an epilogue, that epilogue's stores — the store acknowledgements are never waited for on the critical path
 // (__syncthreads() would drain them: measured ~2 us per tile).
-template <int WN_, int NST, bool HAS_BIAS, bool ATT = false>
+template <int WN_, int NST, bool HAS_BIAS, bool ATT = false, bool RES = false>
 __global__ __launch_bounds__(512, 2) void linear_tn_kernel(const zigma_linear_params_t p, const int tiles_m, const int tiles_n,
                                                            const qattn_extra_t ex = qattn_extra_t{}) {
     constexpr int BM = kLinBM, BN = 64 * WN_, WM_ = 8 / WN_, MB = BM / WM_ / 32, NB = 2;
@@ -429,9 +448,22 @@ __global__ __launch_bounds__(512, 2) void linear_tn_kernel(const zigma_linear_pa
             // tokens beyond m fall outside the extent and are dropped by the hardware
             const rsrc_t o_rs = make_rsrc(reinterpret_cast<unsigned char *>(p.out) + m_tile * o_pitch + (nt * BN + wn * 64) * 2,
                                           rows_here > 0 ? (rows_here < BM / WM_ ? rows_here : BM / WM_) * o_pitch - (nt * BN + wn * 64) * 2 : 0);
-            linear_epilogue<MB, NB>(acc, smem + ((g - 1) % NST) * STAGE + wave * 4096,
-                                    HAS_BIAS ? reinterpret_cast<const uint16_t *>(smem + NST * STAGE) : nullptr, o_rs, o_pitch, nt * BN + wn * 64,
-                                    p.silu_from_col, lane);
+            if constexpr (RES) {
+                // the wave tile (BM / WM_ tokens) lies inside one sample (rows_per_batch % 256 == 0): one gate row, 8 values per lane
+                const int64_t r_pitch = p.res_row_stride * 2;
+                const int n_w = nt * BN + wn * 64;
+                const rsrc_t r_rs = make_rsrc(reinterpret_cast<const unsigned char *>(p.residual) + m_tile * r_pitch + n_w * 2,
+                                              rows_here > 0 ? (rows_here < BM / WM_ ? rows_here : BM / WM_) * r_pitch - n_w * 2 : 0);
+                const int64_t bsm = m_tile / p.rows_per_batch;
+                const uint4 gate8 = *reinterpret_cast<const uint4 *>(reinterpret_cast<const uint16_t *>(p.gate) + bsm * p.gate_batch_stride + n_w + (lane & 7) * 8);
+                linear_epilogue<MB, NB, true>(acc, smem + ((g - 1) % NST) * STAGE + wave * 4096,
+                                              HAS_BIAS ? reinterpret_cast<const uint16_t *>(smem + NST * STAGE) : nullptr, o_rs, o_pitch, n_w,
+                                              p.silu_from_col, lane, r_rs, r_pitch, gate8);
+            } else {
+                linear_epilogue<MB, NB>(acc, smem + ((g - 1) % NST) * STAGE + wave * 4096,
+                                        HAS_BIAS ? reinterpret_cast<const uint16_t *>(smem + NST * STAGE) : nullptr, o_rs, o_pitch, nt * BN + wn * 64,
+                                        p.silu_from_col, lane, o_rs, 0, uint4{});      // (no residual: the last three are not read)
+            }
         }
     }
 }
@@ -459,16 +491,26 @@ extern "C" int zigma_linear_fwd(const zigma_linear_params_t *pp, void *stream_) 
         return ZIGMA_ERR_STRIDE;
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     const int tiles_m = static_cast<int>((p.m + kLinBM - 1) / kLinBM);
-    const bool wide = p.n % 256 == 0 && !(p.flags & 0x1000);      // 0x1000: force the 256 x 128 tile (probe)
+    if (p.residual) {                     // gated residual epilogue: the 256 x 128 tile kernel
+        if (!p.gate || p.rows_per_batch < 1 || p.rows_per_batch % 256 != 0 || p.m % p.rows_per_batch != 0) return ZIGMA_ERR_SHAPE;
+        if (p.res_row_stride % 8 != 0 || p.gate_batch_stride % 8 != 0 || reinterpret_cast<uintptr_t>(p.residual) % 16 != 0 ||
+            reinterpret_cast<uintptr_t>(p.gate) % 16 != 0 || 256 * p.res_row_stride * 2 > 0x7fffffff)
+            return ZIGMA_ERR_STRIDE;
+    }
+    const bool wide = p.n % 256 == 0 && !(p.flags & 0x1000) && !p.residual;      // 0x1000: force the 256 x 128 tile (probe)
     if (p.bias && (p.n > 4096 || reinterpret_cast<uintptr_t>(p.bias) % 4 != 0)) return ZIGMA_ERR_SHAPE;
     const int tiles_n = p.n / (wide ? 256 : 128);
     const int64_t n_tiles = static_cast<int64_t>(tiles_m) * tiles_n;
     if (n_tiles > 0x7fffffff) return ZIGMA_ERR_SHAPE;
     int grid = 256;                                  // one persistent workgroup per CU; multiples of 8 keep the XCD map
     if (n_tiles < grid) grid = static_cast<int>((n_tiles + 7) / 8 * 8);
-#define ZIGMA_LIN(W_, S_, B_) hipLaunchKernelGGL((linear_tn_kernel<W_, S_, B_>), dim3(grid), dim3(512), 0, stream, p, tiles_m, tiles_n)
+#define ZIGMA_LIN(W_, S_, B_) hipLaunchKernelGGL((linear_tn_kernel<W_, S_, B_>), dim3(grid), dim3(512), 0, stream, p, tiles_m, tiles_n, qattn_extra_t{})
     if (wide) { if (p.bias) ZIGMA_LIN(4, 2, true); else ZIGMA_LIN(4, 2, false); }
     else if (p.flags & 0x800) { if (p.bias) ZIGMA_LIN(2, 2, true); else ZIGMA_LIN(2, 2, false); }      // 0x800: two stages (probe)
+    else if (p.residual) {
+        if (p.bias) hipLaunchKernelGGL((linear_tn_kernel<2, 3, true, false, true>), dim3(grid), dim3(512), 0, stream, p, tiles_m, tiles_n, qattn_extra_t{});
+        else hipLaunchKernelGGL((linear_tn_kernel<2, 3, false, false, true>), dim3(grid), dim3(512), 0, stream, p, tiles_m, tiles_n, qattn_extra_t{});
+    }
     else { if (p.bias) ZIGMA_LIN(2, 3, true); else ZIGMA_LIN(2, 3, false); }
 #undef ZIGMA_LIN
     set_last_kernel(wide ? "linear_tn_256x256" : "linear_tn_256x128");

@@ -41,9 +41,12 @@ def linear_eligible(x, weight, bias=None):
     return m * x.stride(-2) * 2 < 2 ** 31 and n * weight.stride(0) * 2 < 2 ** 31 and 256 * n * 2 < 2 ** 31
 
 
-def linear(x, weight, bias=None, silu_from_col=None, out=None, _probe_flags=0):
-    """out = x @ weight.T (+ bias); output columns >= silu_from_col (a multiple of 32) leave as silu(.)"""
-    dev = _lib.require_device(x, weight, bias, out)
+def linear(x, weight, bias=None, silu_from_col=None, out=None, _probe_flags=0, residual=None, gate=None):
+    """out = x @ weight.T (+ bias); output columns >= silu_from_col (a multiple of 32) leave as silu(.).
+    residual (same shape as the result) + gate (batch, n): out = residual + gate[b] * bf16(x @ weight.T + bias) in the kernel's
+    epilogue (the gated branch add of the reference's Block, model_zigma.py:447-449); x must then be (batch, rows, k) with
+    rows % 256 == 0."""
+    dev = _lib.require_device(x, weight, bias, out, residual, gate)
     lead, k = x.shape[:-1], x.shape[-1]
     x2 = x.reshape(-1, k)
     n = weight.shape[0]
@@ -55,5 +58,25 @@ def linear(x, weight, bias=None, silu_from_col=None, out=None, _probe_flags=0):
     P.silu_from_col = n if silu_from_col is None else int(silu_from_col)
     P.x_row_stride, P.w_row_stride, P.out_row_stride = x2.stride(0), weight.stride(0), o2.stride(0)
     P.x, P.w, P.bias, P.out = _lib.ptr(x2), _lib.ptr(weight), _lib.ptr(bias), _lib.ptr(o2)
+    if residual is not None:
+        if gate is None or x.dim() != 3 or residual.shape != (*lead, n) or residual.dtype != x.dtype or gate.dtype != x.dtype \
+                or gate.shape != (x.shape[0], n) or gate.stride(1) != 1 or residual.stride(-1) != 1 or not residual_rows_ok(residual):
+            raise RuntimeError("linear: residual (B, rows, n) with uniform row pitch and gate (B, n) rows in the dtype of x")
+        P.residual, P.gate = _lib.ptr(residual), _lib.ptr(gate)
+        P.res_row_stride, P.gate_batch_stride, P.rows_per_batch = residual.stride(1), gate.stride(0), x.shape[1]
     _lib.call("zigma_linear_fwd", P, dev)
     return out if out.dim() == len(lead) + 1 and out.shape[:-1] == lead else out.view(*lead, n)
+
+
+def residual_rows_ok(residual):
+    """(B, rows, n) whose rows of all samples form ONE sequence of rows of the same pitch"""
+    return residual.dim() == 3 and residual.stride(0) == residual.shape[1] * residual.stride(1)
+
+
+def gated_residual_eligible(x, residual, gate):
+    """limits of the gated-residual epilogue: (B, rows % 256 == 0, k) input, bf16 residual rows 16-byte aligned in one pitch,
+    gate rows 16-byte aligned"""
+    return (x.dim() == 3 and x.shape[1] % 256 == 0 and residual.dtype == x.dtype and gate.dtype == x.dtype and residual_rows_ok(residual)
+            and residual.stride(-1) == 1 and residual.stride(1) % 8 == 0 and residual.data_ptr() % 16 == 0
+            and gate.dim() == 2 and gate.stride(1) == 1 and gate.stride(0) % 8 == 0 and gate.data_ptr() % 16 == 0
+            and 256 * residual.stride(1) * 2 < 2 ** 31)

@@ -30,7 +30,7 @@ from torch import Tensor
 
 from .attention import USE_Q_ATTN, cross_attn, cross_attn_eligible, q_attn, q_attn_eligible, transpose_v
 from .layernorm import RMSNorm, block_norm, layer_norm_fn, rms_norm_fn
-from .linear import linear, linear_eligible
+from .linear import gated_residual_eligible, linear, linear_eligible
 from .mamba_simple import Mamba
 from .scan_paths import hilbert_path, reverse_permut_np, zigzag_path
 
@@ -113,25 +113,37 @@ class CrossAttention(nn.Module):
             return linear(x, lin.weight, lin.bias)
         return F.linear(x, lin.weight, lin.bias)
 
-    def forward(self, x, text, mask=None, kv=None):
+    def _proj_out(self, o, residual, gate):
+        """to_out (+ dropout); with residual / gate the block's gated branch add `residual + gate * to_out(o)` (reference Block,
+        model_zigma.py:447-449) — in the projection kernel's epilogue when its limits are met"""
+        lin = self.to_out[0]
+        if residual is None:
+            return self.to_out[1](self._proj(o, lin))
+        if not self.training and linear_eligible(o, lin.weight, lin.bias) and gated_residual_eligible(o, residual, gate):
+            return linear(o, lin.weight, lin.bias, residual=residual, gate=gate)
+        return torch.addcmul(residual, gate.unsqueeze(1), self.to_out[1](self._proj(o, lin)))
+
+    def forward(self, x, text, mask=None, kv=None, residual=None, gate=None):
         """kv: optional precomputed (to_k(text), to_v(text)), each (B, n_ctx, inner) — ZigMa.forward batches these
-        projections of all layers into one GEMM since `text` is the same for every block."""
+        projections of all layers into one GEMM since `text` is the same for every block.
+        residual (B, L, E), gate (B, E): return residual + gate * attention(x) instead of attention(x)."""
         Bsz, L, _ = x.shape
         H = self.heads
         k, v = kv[:2] if kv is not None else (self.to_k(text), self.to_v(text))
         if USE_Q_ATTN and not torch.is_grad_enabled() and q_attn_eligible(x, self.to_q.weight, k, H):
             # HIP kernels: to_q AND the attention core in one pass (q stays in the accumulators), to_out on the MFMA projection kernel
             vt = kv[2] if kv is not None and len(kv) > 2 else transpose_v(v)
-            return self.to_out[1](self._proj(q_attn(x, self.to_q.weight, k, vt, H, self.scale), self.to_out[0]))
+            return self._proj_out(q_attn(x, self.to_q.weight, k, vt, H, self.scale), residual, gate)
         q = self._proj(x, self.to_q)
         if not torch.is_grad_enabled() and cross_attn_eligible(q, k, v, H):
             # HIP kernels: attention core in one pass (K/V of the head in LDS), to_out on the MFMA projection kernel
-            return self.to_out[1](self._proj(cross_attn(q, k, v, H, self.scale), self.to_out[0]))
+            return self._proj_out(cross_attn(q, k, v, H, self.scale), residual, gate)
         q = q.view(Bsz, L, H, -1).transpose(1, 2)
         k = k.reshape(Bsz, k.shape[1], H, -1).transpose(1, 2)
         v = v.reshape(Bsz, v.shape[1], H, -1).transpose(1, 2)
         o = F.scaled_dot_product_attention(q, k, v)
-        return self.to_out(o.transpose(1, 2).reshape(Bsz, L, -1))
+        out = self.to_out(o.transpose(1, 2).reshape(Bsz, L, -1))
+        return out if residual is None else torch.addcmul(residual, gate.unsqueeze(1), out)
 
 
 def drop_path(x, drop_prob: float = 0.0, training: bool = False, scale_by_keep: bool = True):
@@ -274,8 +286,8 @@ class Block(nn.Module):
         h, _, _, xa = block_norm(n, None, None, None, self.norm_msa.eps, False, residual_in_fp32=False, branch=mix,
                                  gate=mod[:, 2 * E:3 * E], shift=mod[:, 3 * E:4 * E], scale=mod[:, 4 * E:5 * E],
                                  want_x=True, want_y=False, want_res_out=False)
-        att = self.msa(xa, text=text, mask=None, kv=kv)
-        return Pending(h, att, mod[:, 5 * E:6 * E]), residual
+        # h + gate_msa * attention(xa): the add rides in to_out's epilogue (one read of att less for the next block's add + norm)
+        return Pending(self.msa(xa, text=text, mask=None, kv=kv, residual=h, gate=mod[:, 5 * E:6 * E])), residual
 
     def forward(self, x: Tensor, residual: Optional[Tensor] = None, c=None, text=None, inference_params=None, skip=None):
         if self.skip_linear is not None:
