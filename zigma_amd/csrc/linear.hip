@@ -55,6 +55,13 @@ __device__ __forceinline__ void linear_epilogue(const f32x16 (&acc)[NB][MB], uns
     const unsigned scr_lds = static_cast<unsigned>(reinterpret_cast<uintptr_t>((lds_ptr_t)(scr)));      // LDS byte address
 #pragma unroll
     for (int mb = 0; mb < MB; ++mb) {
+        typedef unsigned u4 __attribute__((ext_vector_type(4)));
+        u4 res[4];
+        if constexpr (RES) {                          // requested first: the latency runs under the conversion / transposition below
+            const unsigned rs_off = static_cast<unsigned>(rd_tok * r_pitch + (lane & 7) * 16);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) res[i] = __builtin_amdgcn_raw_buffer_load_b128(r_rs, rs_off, static_cast<int>((mb * 32 + i * 8) * r_pitch), 0);
+        }
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb) {
             const int n0 = n_wave0 + nb * 32;                                                  // wave-uniform
@@ -95,17 +102,12 @@ __device__ __forceinline__ void linear_epilogue(const f32x16 (&acc)[NB][MB], uns
         }
         // wave-private scratch: writes and reads of one wave execute in order in the LDS queue; the reads' data is waited for
         // explicitly (inline asm again: no drain of the load ring in front of them)
-        typedef unsigned u4 __attribute__((ext_vector_type(4)));
         u4 row[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i)
             asm volatile("ds_read_b128 %0, %1" : "=v"(row[i]) : "v"(scr_lds + i * 1024 + rd_tok * 128 + ((rd_slot ^ ((i & 1) << 2)) << 4)));
         asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(row[0]), "+v"(row[1]), "+v"(row[2]), "+v"(row[3]));
         if constexpr (RES) {
-            const unsigned rs_off = static_cast<unsigned>(rd_tok * r_pitch + (lane & 7) * 16);
-            u4 res[4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) res[i] = __builtin_amdgcn_raw_buffer_load_b128(r_rs, rs_off, static_cast<int>((mb * 32 + i * 8) * r_pitch), 0);
             const unsigned gq[4] = {gate8.x, gate8.y, gate8.z, gate8.w};
 #pragma unroll
             for (int i = 0; i < 4; ++i)

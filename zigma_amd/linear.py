@@ -17,12 +17,12 @@ import os
 LINEAR_POLICY = os.environ.get("ZIGMA_LINEAR", "auto")
 
 
-def linear_eligible(x, weight, bias=None):
+def linear_eligible(x, weight, bias=None, fused_epilogue=False):
     """policy (LINEAR_POLICY) + limits of zigma_linear_fwd: bf16, k % 64 == 0, n % 128 == 0, tokens % 8 == 0, aligned contiguous
     rows, no autograd"""
     if not (LINEAR_POLICY != "off" and x.is_cuda and x.dtype == torch.bfloat16 and weight.dtype == torch.bfloat16):
         return False
-    if LINEAR_POLICY == "auto" and bias is None:
+    if LINEAR_POLICY == "auto" and bias is None and not fused_epilogue:       # (an epilogue the library cannot fuse is a reason too)
         return False
     if torch.is_grad_enabled() and (x.requires_grad or weight.requires_grad or (bias is not None and bias.requires_grad)):
         return False

@@ -14,7 +14,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from .linear import linear, linear_eligible
+from .linear import gated_residual_eligible, linear, linear_eligible
 from .selective_scan_interface import mamba_inner_tok
 
 
@@ -141,8 +141,27 @@ class Mamba(nn.Module):
             dt_proj.bias.copy_(inv_dt)
         dt_proj.bias._no_reinit = True
 
-    def forward(self, hidden_states, inference_params=None):
-        return self._mamba_inner_forward(hidden_states, inference_params)
+    def forward(self, hidden_states, inference_params=None, residual=None, gate=None):
+        """residual (B, L, E) + gate (B, E): returns residual + gate[:, None] * mixer(hidden_states) — the block's gated branch add
+        (reference model_zigma.py:441-445), carried by out_proj's epilogue when the projection kernel's limits are met."""
+        y = self._mamba_inner_forward(hidden_states, inference_params)
+        lin = self.out_proj
+        if residual is None:
+            return self._proj(y, lin)
+        if (not torch.is_grad_enabled() and linear_eligible(y, lin.weight, lin.bias, fused_epilogue=True)
+                and gated_residual_eligible(y, residual, gate)):
+            return linear(y, lin.weight, lin.bias, residual=residual, gate=gate)
+        return torch.addcmul(residual, gate.unsqueeze(1), self._proj(y, lin))
+
+    def out_add_fusable(self, residual, gate):
+        """True when forward(..., residual=, gate=) will carry the gated add in out_proj's epilogue (no-grad, bf16, 256-row samples)"""
+        lin = self.out_proj
+        if torch.is_grad_enabled() or not residual.is_cuda or residual.dtype != torch.bfloat16 or residual.dim() != 3:
+            return False
+        y = torch.empty(residual.shape[0], residual.shape[1], self.d_inner, device="meta", dtype=residual.dtype)   # shape / dtype stand-in
+        return (residual.shape[1] * residual.shape[0] >= 16384 and lin.weight.dtype == torch.bfloat16 and self.d_inner % 64 == 0
+                and lin.weight.shape[0] % 128 == 0 and gated_residual_eligible(y, residual, gate)
+                and (lin.bias is None or lin.bias.dtype == torch.bfloat16))
 
     def _scan_consts(self, sfx):
         """(A = -exp(A_log), D, dt_bias) in float32, as the reference passes them to the scan
@@ -177,7 +196,7 @@ class Mamba(nn.Module):
         return self._rev_cache[key]
 
     def _mamba_inner_forward(self, hidden_states, inference_params=None):
-        """hidden_states: (B, L, D) -> (B, L, D)."""
+        """hidden_states: (B, L, D) -> the gated scan output (B, L, d_inner), before out_proj."""
         if inference_params is not None:
             raise NotImplementedError("zigma_amd: recurrent decoding is out of scope (ZigMa never passes inference_params)")
         batch, seqlen, _ = hidden_states.shape
@@ -225,7 +244,7 @@ class Mamba(nn.Module):
                 raise NotImplementedError
         else:
             raise NotImplementedError
-        return self._proj(y, self.out_proj)
+        return y                                                                    # (out_proj: forward())
 
     @staticmethod
     def _proj(x, lin):

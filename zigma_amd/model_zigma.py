@@ -18,6 +18,7 @@ What is different underneath (sampling / eval forward):
     in the input dtype, so an fp32 ODE state can drive a bf16 model.
 """
 import math
+import os
 from functools import partial
 from typing import Optional
 
@@ -249,6 +250,13 @@ class Pending:
         return torch.addcmul(self.base, self.gate.unsqueeze(1), self.branch)
 
 
+# out_proj on the own projection kernel WITH the block's gated add `n + gate_msa * mixer(.)` in its epilogue, instead of the library
+# GEMM + the add inside the following norm kernel.  Per block (profiles/r02_b_bench_kernel_stats.csv vs r02_d_*): out_proj 127 -> 150 us,
+# pre-attention add + norm 68 -> 47, and with to_out's gated add: to_out 63 -> 78, pre-mixer add + norm 119 -> 102 — time moves from
+# the HBM-bound norm kernels into the projection epilogues, the forward is 0.1-0.3 % faster.  ZIGMA_OUT_PROJ_FUSED=0: library out_proj.
+FUSE_OUT_PROJ_ADD = os.environ.get("ZIGMA_OUT_PROJ_FUSED", "1") != "0"
+
+
 class Block(nn.Module):
     def __init__(self, dim, mixer_cls, has_text=False, norm_cls=nn.LayerNorm, fused_add_norm=False,
                  residual_in_fp32=False, drop_path=0.0, skip=False):
@@ -280,6 +288,14 @@ class Block(nn.Module):
         _, residual, n, xm = block_norm(pend.base, self.norm.weight, self.norm.bias, residual, self.norm.eps, is_rms,
                                         residual_in_fp32=self.residual_in_fp32, branch=pend.branch, gate=pend.gate,
                                         shift=mod[:, 0:E], scale=mod[:, E:2 * E])
+        if FUSE_OUT_PROJ_ADD and self.mixer.out_add_fusable(n, mod[:, 2 * E:3 * E]):
+            # n + gate_msa * mixer(xm) in out_proj's epilogue (own projection kernel): the following norm reads one tensor, writes one
+            h = self.mixer(xm, residual=n, gate=mod[:, 2 * E:3 * E])
+            if not self.has_text:
+                return Pending(h), residual
+            _, _, _, xa = block_norm(h, None, None, None, self.norm_msa.eps, False, residual_in_fp32=False,
+                                     shift=mod[:, 3 * E:4 * E], scale=mod[:, 4 * E:5 * E], want_x=False, want_y=False, want_res_out=False)
+            return Pending(self.msa(xa, text=text, mask=None, kv=kv, residual=h, gate=mod[:, 5 * E:6 * E])), residual
         mix = self.mixer(xm)
         if not self.has_text:
             return Pending(n, mix, mod[:, 2 * E:3 * E]), residual
