@@ -10,9 +10,10 @@
 
 namespace zigma {
 
-__device__ __forceinline__ float wave_sum(float v) {
+// sum over the LPR lanes that share a row (LPR = 64: the whole wave)
+template <int LPR> __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
-    for (int s = 32; s > 0; s >>= 1) v += __shfl_xor(v, s, 64);
+    for (int s = LPR / 2; s > 0; s >>= 1) v += __shfl_xor(v, s, 64);
     return v;
 }
 
@@ -79,12 +80,14 @@ template <typename T, int VEC> __device__ __forceinline__ void storev(void *base
 // value the tensor would hold after being stored in dtype T (the reference materialises these tensors)
 template <typename T> __device__ __forceinline__ float rnd(float v) { return to_float<T>(from_float<T>(v)); }
 
-// VEC = 4 (vector path) or 1 (scalar path, any alignment); ITERS chunks of 64*VEC columns per row.
-template <typename XT, typename RT, typename WT, typename MT, int VEC, int ITERS>
+// VEC = 8 / 4 (vector paths) or 1 (scalar path, any alignment); a row is shared by LPR lanes (64 / LPR rows per wave) that walk it in
+// ITERS chunks of LPR * VEC columns.  LPR = 16 is for rows of a few hundred 16-bit elements (E = 640: 5 x 16 bytes per lane, every
+// lane busy, 4 rows per wave instruction and per reduction step); LPR = 64 is one row per wave.
+template <typename XT, typename RT, typename WT, typename MT, int VEC, int ITERS, int LPR = 64>
 __global__ __launch_bounds__(256) void add_norm_kernel(const zigma_norm_params_t p) {
-    const int lane = threadIdx.x & 63;
-    const int64_t r = static_cast<int64_t>(blockIdx.x) * 4 + (threadIdx.x >> 6);
-    if (r >= p.rows) return;
+    const int lane = (threadIdx.x & 63) % LPR;
+    const int64_t r = (static_cast<int64_t>(blockIdx.x) * 4 + (threadIdx.x >> 6)) * (64 / LPR) + (threadIdx.x & 63) / LPR;
+    if (r >= p.rows) return;            // (rows % (64 / LPR) == 0 on the multi-row path: whole waves leave together)
     const int b = static_cast<int>(r / p.rows_per_batch);
     const int cols = p.cols;
 
@@ -92,7 +95,7 @@ __global__ __launch_bounds__(256) void add_norm_kernel(const zigma_norm_params_t
     float sum = 0.f, sq = 0.f;
 #pragma unroll
     for (int it = 0; it < ITERS; ++it) {
-        const int c = (it * 64 + lane) * VEC;
+        const int c = (it * LPR + lane) * VEC;
         if (c < cols) {
             float x[VEC];
             loadv<XT, VEC>(p.x, r * p.x_row_stride + c, x);
@@ -124,23 +127,23 @@ __global__ __launch_bounds__(256) void add_norm_kernel(const zigma_norm_params_t
     }
     float mean = 0.f, rstd;
     if (p.is_rms) {
-        rstd = rsqrtf(wave_sum(sq) / cols + p.eps);
+        rstd = rsqrtf(wave_sum<LPR>(sq) / cols + p.eps);
     } else {  // two-pass variance on the register copy, like the Triton kernel (layernorm.py:102-107)
-        mean = wave_sum(sum) / cols;
+        mean = wave_sum<LPR>(sum) / cols;
         float var = 0.f;
 #pragma unroll
         for (int it = 0; it < ITERS; ++it) {
-            const int c = (it * 64 + lane) * VEC;
+            const int c = (it * LPR + lane) * VEC;
             if (c < cols) {
 #pragma unroll
                 for (int i = 0; i < VEC; ++i) { const float dlt = v[it][i] - mean; var += dlt * dlt; }
             }
         }
-        rstd = rsqrtf(wave_sum(var) / cols + p.eps);
+        rstd = rsqrtf(wave_sum<LPR>(var) / cols + p.eps);
     }
 #pragma unroll
     for (int it = 0; it < ITERS; ++it) {
-        const int c = (it * 64 + lane) * VEC;
+        const int c = (it * LPR + lane) * VEC;
         if (c < cols) {
             float y[VEC], w[VEC], bs[VEC];
 #pragma unroll
@@ -184,6 +187,26 @@ static int launch_norm(const zigma_norm_params_t &p, hipStream_t stream) {
                       al(p.shift, 8 * ms) && al(p.scale, 8 * ms) && xs == 2;
     dim3 grid(static_cast<unsigned>((static_cast<int64_t>(p.rows) + 3) / 4)), block(256);
 #define ZIGMA_NORM(V_, I_) hipLaunchKernelGGL((add_norm_kernel<XT, RT, WT, MT, V_, I_>), grid, block, 0, stream, p)
+    // four rows per wave where a row is light (16-bit tensors only: 32 us against 44 for the pre-attention LayerNorm of the block);
+    // with the fp32 residual stream in and out a row is 5-6 KB and one row per wave is the faster form (117 against 121 us)
+    const bool light_rows = (p.residual == nullptr && p.residual_out == nullptr) || rs == 2;
+    if (vec8 && light_rows && p.cols % 128 == 0 && p.cols <= 128 * 8 && p.rows % 4 == 0 && !(p.flags & 1)) {
+        const dim3 grid4(static_cast<unsigned>((static_cast<int64_t>(p.rows) / 4 + 3) / 4));
+#define ZIGMA_NORM4(I_) hipLaunchKernelGGL((add_norm_kernel<XT, RT, WT, MT, 8, I_, 16>), grid4, block, 0, stream, p)
+        switch (p.cols / 128) {
+            case 1: ZIGMA_NORM4(1); break;
+            case 2: ZIGMA_NORM4(2); break;
+            case 3: ZIGMA_NORM4(3); break;
+            case 4: ZIGMA_NORM4(4); break;
+            case 5: ZIGMA_NORM4(5); break;
+            case 6: ZIGMA_NORM4(6); break;
+            case 7: ZIGMA_NORM4(7); break;
+            default: ZIGMA_NORM4(8); break;
+        }
+#undef ZIGMA_NORM4
+        set_last_kernel("add_norm_v8x4");
+        return check_launch();
+    }
     if (vec8 && p.cols <= 512 * 2) ZIGMA_NORM(8, 2);       // 16-byte accesses for 16-bit activations
     else if (vec && p.cols <= 256 * 4) ZIGMA_NORM(4, 4);
     else if (vec && p.cols <= 256 * 16) ZIGMA_NORM(4, 16);
@@ -209,7 +232,7 @@ extern "C" int zigma_add_norm_fwd(const zigma_norm_params_t *pp, void *stream_) 
     if (p.shift && !p.y_mod) return ZIGMA_ERR_NULL;
     if (!p.y_out && !p.y_mod) return ZIGMA_ERR_NULL;
     if (p.rows < 0 || p.cols < 1 || p.rows_per_batch < 1) return ZIGMA_ERR_SHAPE;
-    if (p.flags != 0) return ZIGMA_ERR_UNSUPPORTED;
+    if (p.flags & ~1) return ZIGMA_ERR_UNSUPPORTED;          // 1: one row per wave even where four fit (A/B probe)
     if (p.rows == 0) return ZIGMA_OK;
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     // residual stream is f32 or the activation dtype; weights f32 or activation dtype; keep the

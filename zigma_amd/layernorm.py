@@ -6,7 +6,11 @@ and adds `block_norm`, the ZigMa-block form with the gated branch add and adaLN 
 """
 import torch
 
+import os
+
 from . import _lib
+
+NORM_FLAGS = 1 if os.environ.get("ZIGMA_NORM_ONE_ROW") == "1" else 0      # 1: one row per wave even where four fit (A/B probe)
 
 
 def _norm_call(x2, weight, bias, residual2, eps, is_rms, residual_dtype, *, rows_per_batch=None, branch=None,
@@ -16,7 +20,7 @@ def _norm_call(x2, weight, bias, residual2, eps, is_rms, residual_dtype, *, rows
     P = _lib.NormParams()
     P.rows, P.cols = rows, cols
     P.rows_per_batch = rows_per_batch or max(rows, 1)
-    P.is_rms, P.eps, P.flags = int(is_rms), float(eps), 0
+    P.is_rms, P.eps, P.flags = int(is_rms), float(eps), NORM_FLAGS
     P.x_dtype = _lib.dtype_id(x2)
     P.x, P.x_row_stride = _lib.ptr(x2), x2.stride(0)
     y = y_mod = res_out = None
