@@ -10,8 +10,9 @@
 //
 // One wave = 32 tokens x 64 channels: v_mfma_f32_32x32x16_bf16, 3 k-steps (K padded to 48 with zero fragments),
 // two accumulators.  The B fragments of the two accumulators hold the EVEN and the ODD channels of the 64-channel
-// slab, so lane j ends up with channels 2j and 2j+1 of each token: one v_cvt_pk_bf16_f32 + one 4-byte store per
-// token, 128 contiguous bytes per row per wave.  A / B fragments are 16-byte loads straight from global
+// slab, so lane j ends up with channels 2j and 2j+1 of each token: one v_cvt_pk_bf16_f32 per token and pair; the tile is
+// then transposed through a wave-private LDS tile and leaves as 16-byte stores (8 tokens x 128 B per instruction: 16 four-byte
+// stores per lane made the store instruction rate the limit, 62-66 -> 59-60 us).  A / B fragments are 16-byte loads straight from global
 // (x_dbl is 9 MB, the weight 100 KB: L2 resident), no LDS.
 #include "zigma_common.h"
 
@@ -27,9 +28,11 @@ constexpr int kDtTokPerWave = 32, kDtChPerBlock = 64, kDtWaves = 4;
 constexpr int kDtIters = ZIGMA_DT_ITERS;
 
 __global__ __launch_bounds__(64 * kDtWaves) void dt_proj_softplus_kernel(const zigma_dtproj_params_t p) {
+    __shared__ __attribute__((aligned(16))) unsigned char s_tile[kDtWaves * kDtTokPerWave * 144];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int d0 = blockIdx.x * kDtChPerBlock;
+    const bool wide_ok = p.out_row_stride % 8 == 0 && reinterpret_cast<uintptr_t>(p.out) % 16 == 0 && !(p.flags & 1);   // 16-byte stores
     const int j = lane & 31, kh = lane >> 5;                   // fragment row / k-half of this lane
     const uint16_t *xw = reinterpret_cast<const uint16_t *>(p.x);
     const uint16_t *ww = reinterpret_cast<const uint16_t *>(p.w);
@@ -79,6 +82,24 @@ __global__ __launch_bounds__(64 * kDtWaves) void dt_proj_softplus_kernel(const z
         }
         // C/D layout: column = lane & 31 (channel pair j), row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5) (token)
         const bool full = m0 + kDtTokPerWave <= p.m;            // wave-uniform: whole tile inside -> no per-store predicate
+        if (full && wide_ok) {
+            // 16 four-byte stores per lane make the store INSTRUCTION rate the limit (2560 per CU at the headline shape); the tile goes
+            // through a wave-private LDS tile (32 tokens x 128 B, pitch 144) and leaves as 4 sixteen-byte stores per lane
+            unsigned char *tile = s_tile + wave * (kDtTokPerWave * 144);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int dm = (r & 3) + 8 * (r >> 2) + 4 * kh;
+                float ve = ce[r] + b_e, vo = co[r] + b_o;
+                if (p.softplus) { ve = softplus20_r16(ve); vo = softplus20_r16(vo); }
+                *reinterpret_cast<uint32_t *>(tile + dm * 144 + j * 4) =
+                    static_cast<uint32_t>(from_float<BF16>(ve)) | (static_cast<uint32_t>(from_float<BF16>(vo)) << 16);
+            }
+            uint16_t *orow8 = ow + (m0 + (lane >> 3)) * p.out_row_stride + d0 + (lane & 7) * 8;
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                *reinterpret_cast<uint4 *>(orow8 + static_cast<int64_t>(i * 8) * p.out_row_stride) =
+                    *reinterpret_cast<const uint4 *>(tile + (i * 8 + (lane >> 3)) * 144 + (lane & 7) * 16);
+        } else {
         uint16_t *orow = ow + (m0 + 4 * kh) * p.out_row_stride + d0 + 2 * j;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -87,6 +108,7 @@ __global__ __launch_bounds__(64 * kDtWaves) void dt_proj_softplus_kernel(const z
             if (p.softplus) { ve = softplus20_r16(ve); vo = softplus20_r16(vo); }
             const uint32_t pk = static_cast<uint32_t>(from_float<BF16>(ve)) | (static_cast<uint32_t>(from_float<BF16>(vo)) << 16);
             if (full || m0 + 4 * kh + dm < p.m) *reinterpret_cast<uint32_t *>(orow + dm * p.out_row_stride) = pk;
+        }
         }
 #pragma unroll
         for (int s = 0; s < 3; ++s) a_cur[s] = a_nxt[s];
@@ -102,7 +124,7 @@ extern "C" int zigma_dt_proj_softplus_fwd(const zigma_dtproj_params_t *pp, void 
     (void)hipGetLastError();
     const zigma_dtproj_params_t &p = *pp;
     if (p.m < 0 || p.n < 0 || p.k < 1) return ZIGMA_ERR_SHAPE;
-    if (p.flags != 0) return ZIGMA_ERR_UNSUPPORTED;
+    if (p.flags & ~1) return ZIGMA_ERR_UNSUPPORTED;         // 1: four-byte stores as the accumulators lie (A/B probe)
     if (p.m == 0 || p.n == 0) return ZIGMA_OK;
     if (!p.x || !p.w || !p.out) return ZIGMA_ERR_NULL;
     if (p.dtype != ZIGMA_BF16) return ZIGMA_ERR_DTYPE;

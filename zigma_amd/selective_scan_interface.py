@@ -33,6 +33,7 @@ CONV_X_PROJ_MIN_POSITIONS = int(os.environ.get("ZIGMA_CONV_XPROJ_MIN", "16384"))
 # (138.7 us against 71.3 + 64 = 135.7: inside one workgroup the phases add up, and the VALU / store-bound dt phase runs at the
 # 2 waves per SIMD of the 200-register main loop instead of its own 4) — off unless ZIGMA_CONV_XPROJ_DT=1
 USE_CONV_X_PROJ_DT = os.environ.get("ZIGMA_CONV_XPROJ_DT", "0") == "1"
+DT_PROJ_FLAGS = 1 if os.environ.get("ZIGMA_DT_PROJ_NARROW_STORES") == "1" else 0     # 1: four-byte stores (A/B probe)
 USE_X_PROJ_KERNEL = True      # own MFMA kernel for the skinny x_proj instead of the library GEMM (same speed stand-alone)
 SPLIT_MAX_WGS = 200          # ... and sweeps this: split when batch * d_inner / 64 is at most this many workgroups (tools/split_threshold_probe.py)
 
@@ -281,7 +282,7 @@ def dt_proj_softplus(x_dbl, dt_rank, weight, bias=None, softplus=True):
     out = torch.empty(x2.shape[0], n, device=x_dbl.device, dtype=x_dbl.dtype)
     P = _lib.DtProjParams()
     P.m, P.n, P.k = x2.shape[0], n, dt_rank
-    P.dtype, P.softplus, P.flags = _lib.dtype_id(x_dbl), int(bool(softplus)), 0
+    P.dtype, P.softplus, P.flags = _lib.dtype_id(x_dbl), int(bool(softplus)), DT_PROJ_FLAGS
     P.x_row_stride, P.w_row_stride, P.out_row_stride = x2.stride(0), weight.stride(0), out.stride(0)
     P.x, P.w, P.out = _lib.ptr(x2), _lib.ptr(weight), _lib.ptr(out)
     if bias is not None:
