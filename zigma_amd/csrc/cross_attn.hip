@@ -24,14 +24,15 @@ constexpr int kXaD = 64;                 // head dim
 constexpr int kXaWaves = 4, kXaTok = 16; // tokens per wave (MFMA M)
 constexpr int kXaKPitch = (kXaD + 8) * 2;   // bytes per K row in LDS (16 B skew)
 
-constexpr int kXaTiles = 4;              // 16-token tiles per wave: K/V of the head are staged once per 256 tokens
+// 16-token tiles per wave = how many query tokens share one staging of K_h / V_h^T (20 KB): 8 (512 tokens per workgroup) where the
+// sequence has them — 35.5 us against 38.0 with 4 and 40.2 with 16 at the headline shape (tools/attn_probe.py) —, 4 for short ones
 
 __device__ __forceinline__ uint32_t pack_bf16(float lo, float hi) {
     return static_cast<uint32_t>(from_float<BF16>(lo)) | (static_cast<uint32_t>(from_float<BF16>(hi)) << 16);
 }
 
 template <int NKB>                       // 16-key blocks: n_ctx <= 16 * NKB
-__global__ __launch_bounds__(64 * kXaWaves) void cross_attn_kernel(const zigma_xattn_params_t p) {
+__global__ __launch_bounds__(64 * kXaWaves) void cross_attn_kernel(const zigma_xattn_params_t p, const int kXaTiles) {
     constexpr int KP = 16 * NKB;                         // keys covered by S
     constexpr int KS = (KP + 31) / 32, KP2 = 32 * KS;    // k-steps / padded keys of the P V product
     constexpr int VPitch = (KP2 + 8) * 2;                // bytes per row of V^T and of P (16 B skew)
@@ -184,11 +185,12 @@ extern "C" int zigma_cross_attn_fwd(const zigma_xattn_params_t *pp, void *stream
     if (mis(p.q, p.q_row_stride, p.q_batch_stride) || mis(p.k, p.k_row_stride, p.k_batch_stride) ||
         mis(p.v, p.v_row_stride, p.v_batch_stride) || mis(p.out, p.o_row_stride, p.o_batch_stride))
         return ZIGMA_ERR_STRIDE;
-    const int tok_per_wg = kXaTok * kXaWaves * kXaTiles;
+    const int tiles = p.seqlen >= 512 ? 8 : 4;
+    const int tok_per_wg = kXaTok * kXaWaves * tiles;
     dim3 grid((p.seqlen + tok_per_wg - 1) / tok_per_wg, p.heads, p.batch), block(64 * kXaWaves);
     hipStream_t stream = static_cast<hipStream_t>(stream_);
-    if (p.n_ctx <= 80) hipLaunchKernelGGL(cross_attn_kernel<5>, grid, block, 0, stream, p);
-    else hipLaunchKernelGGL(cross_attn_kernel<8>, grid, block, 0, stream, p);
+    if (p.n_ctx <= 80) hipLaunchKernelGGL(cross_attn_kernel<5>, grid, block, 0, stream, p, tiles);
+    else hipLaunchKernelGGL(cross_attn_kernel<8>, grid, block, 0, stream, p, tiles);
     set_last_kernel("cross_attn_mfma");
     return check_launch();
 }
