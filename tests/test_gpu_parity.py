@@ -462,6 +462,36 @@ def test_empty_inputs():
     assert causal_conv1d_fn(u, torch.randn(4, 4, device=DEV)).shape == (0, 4, 16)
 
 
+def test_new_entry_points_reject_what_they_cannot_do():
+    """Error behaviour of the round-2 entry points: shapes / strides outside their limits raise (status codes of the C ABI surface as
+    RuntimeError), nothing is silently computed another way."""
+    from zigma_amd.attention import q_attn, transpose_v
+    from zigma_amd.linear import linear
+    from zigma_amd.selective_scan_interface import conv_x_proj
+    bf = torch.bfloat16
+    x = torch.randn(2, 128, 128, device=DEV, dtype=bf)
+    cw, cb = torch.randn(64, 4, device=DEV, dtype=bf), torch.randn(64, device=DEV, dtype=bf)
+    with pytest.raises(RuntimeError):                            # n not a multiple of 8
+        conv_x_proj(x[:, :, :64], cw, cb, torch.randn(73, 64, device=DEV, dtype=bf))
+    with pytest.raises(RuntimeError):                            # seqlen not a multiple of 32
+        conv_x_proj(torch.randn(2, 136, 128, device=DEV, dtype=bf)[:, :, :64], cw, cb, torch.randn(72, 64, device=DEV, dtype=bf))
+    with pytest.raises(RuntimeError):                            # d_inner not a multiple of 64
+        conv_x_proj(torch.randn(2, 128, 96, device=DEV, dtype=bf)[:, :, :48], cw[:48], cb[:48], torch.randn(72, 48, device=DEV, dtype=bf))
+    with pytest.raises(RuntimeError):                            # dt product: rank not a multiple of 8
+        conv_x_proj(x[:, :, :64], cw, cb, torch.randn(72, 64, device=DEV, dtype=bf), dt_weight=torch.randn(64, 12, device=DEV, dtype=bf))
+    xq = torch.randn(1, 256, 64, device=DEV, dtype=bf)
+    wq = torch.randn(256, 64, device=DEV, dtype=bf)
+    kv = torch.randn(1, 90, 2, 256, device=DEV, dtype=bf)
+    with pytest.raises(RuntimeError):                            # 90 keys: beyond what the attention phase stages
+        q_attn(xq, wq, kv[:, :, 0], transpose_v(kv[:, :, 1]), 4)
+    with pytest.raises(RuntimeError):                            # seqlen not a multiple of the 256-token tile
+        q_attn(torch.randn(1, 128, 64, device=DEV, dtype=bf), wq, kv[:, :77, 0], transpose_v(kv[:, :77, 1]), 4)
+    xl = torch.randn(2, 128, 64, device=DEV, dtype=bf)
+    with pytest.raises(RuntimeError):                            # gated residual: samples of 128 rows (tiles would straddle samples)
+        linear(xl, torch.randn(128, 64, device=DEV, dtype=bf), None, residual=torch.randn(2, 128, 128, device=DEV, dtype=bf),
+               gate=torch.randn(2, 128, device=DEV, dtype=bf))
+
+
 def test_graphed_forward_matches_eager_and_sampler_runs_on_it():
     from zigma_amd.graphs import GraphedForward
     from zigma_amd.transport import Sampler, create_transport
