@@ -9,21 +9,25 @@ import os
 
 # Which projections run on zigma_linear_fwd.  Measured at the headline shapes, own kernel vs hipBLASLt in us (stand-alone:
 # tools/linear_probe.py, profiles/r02_linear_probe.jsonl; inside the forward: profiles/r02_b_bench_kernel_stats.csv):
-#   to_out (bias) 54.6 vs 68.0 stand-alone, 61 vs 71 in the forward;  out_proj 119.6 vs 115.3 stand-alone but 153 vs 127 in the
-#   forward (its operand was just written by the scan: the one-step-deep prefetch shows the HBM latency);  to_q 47.5 vs 42.9;
-#   in_proj 240.6 vs 190.6.
-#   "auto" (default): projections with a bias (to_out), where the kernel beats the library;  "all": every eligible projection;
-#   "off": library only.
+#   to_out (bias) 55-60 vs 66-68;  out_proj 119-124 vs 115-118 stand-alone, 150 (WITH the block's gated add in its epilogue) vs 127
+#   in the forward;  to_q 47.5 vs 42.4;  in_proj 241 vs 188-194.
+#   "auto" (default): the projections whose epilogue the library cannot fuse — to_out (bias + gated add) and, in text blocks,
+#   out_proj (gated add; model_zigma.FUSE_OUT_PROJ_ADD) — the rest (in_proj, to_q) on the library;  "all": every eligible
+#   projection on the own kernel (the forward is then ~5 % slower);  "off": library only.
 LINEAR_POLICY = os.environ.get("ZIGMA_LINEAR", "auto")
 
 
-def linear_eligible(x, weight, bias=None, fused_epilogue=False):
+# to_q on the own kernel under "auto": + 9 us per block inside the forward (18.77 vs 18.60 ms, same box) — off unless ZIGMA_TO_Q_OWN=1
+TO_Q_OWN = os.environ.get("ZIGMA_TO_Q_OWN", "0") == "1"
+
+
+def linear_eligible(x, weight, bias=None, fused_epilogue=False, prefer_own=False):
     """policy (LINEAR_POLICY) + limits of zigma_linear_fwd: bf16, k % 64 == 0, n % 128 == 0, tokens % 8 == 0, aligned contiguous
     rows, no autograd"""
     if not (LINEAR_POLICY != "off" and x.is_cuda and x.dtype == torch.bfloat16 and weight.dtype == torch.bfloat16):
         return False
-    if LINEAR_POLICY == "auto" and bias is None and not fused_epilogue:       # (an epilogue the library cannot fuse is a reason too)
-        return False
+    if LINEAR_POLICY == "auto" and bias is None and not fused_epilogue and not prefer_own:   # (an epilogue the library cannot fuse is a
+        return False                                                                           #  reason too)
     if torch.is_grad_enabled() and (x.requires_grad or weight.requires_grad or (bias is not None and bias.requires_grad)):
         return False
     n, k = weight.shape

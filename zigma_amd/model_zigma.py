@@ -31,7 +31,7 @@ from torch import Tensor
 
 from .attention import USE_Q_ATTN, cross_attn, cross_attn_eligible, q_attn, q_attn_eligible, transpose_v
 from .layernorm import RMSNorm, block_norm, layer_norm_fn, rms_norm_fn
-from .linear import gated_residual_eligible, linear, linear_eligible
+from .linear import TO_Q_OWN, gated_residual_eligible, linear, linear_eligible
 from .mamba_simple import Mamba
 from .scan_paths import hilbert_path, reverse_permut_np, zigzag_path
 
@@ -135,7 +135,10 @@ class CrossAttention(nn.Module):
             # HIP kernels: to_q AND the attention core in one pass (q stays in the accumulators), to_out on the MFMA projection kernel
             vt = kv[2] if kv is not None and len(kv) > 2 else transpose_v(v)
             return self._proj_out(q_attn(x, self.to_q.weight, k, vt, H, self.scale), residual, gate)
-        q = self._proj(x, self.to_q)
+        if TO_Q_OWN and linear_eligible(x, self.to_q.weight, None, prefer_own=True):
+            q = linear(x, self.to_q.weight, None)          # the whole attention branch on hand-written kernels (+ 5 us against the library)
+        else:
+            q = self._proj(x, self.to_q)
         if not torch.is_grad_enabled() and cross_attn_eligible(q, k, v, H):
             # HIP kernels: attention core in one pass (K/V of the head in LDS), to_out on the MFMA projection kernel
             return self._proj_out(cross_attn(q, k, v, H, self.scale), residual, gate)
