@@ -332,6 +332,31 @@ __global__ __launch_bounds__(512, 2) void linear_tn_kernel(const zigma_linear_pa
         ++is_g;
         if (++is_kt == nk) { is_kt = 0; is_tile += wg_per_xcd; }
     };
+    // the same batch in pieces, for the main loop: the direct-to-LDS instructions cost 60-180 cycles of issue each and, fired back to
+    // back at the top of a k-step by every wave, leave the matrix pipe idle for their whole burst; spread between the MFMAs of the
+    // first two sub-steps they cost the wave what they cost, and the pipe keeps running on its partner's MFMAs
+    const unsigned char *ip_w = nullptr, *ip_x = nullptr;
+    unsigned char *ip_dst = nullptr;
+    int64_t ip_rows_left = 0;
+    auto issue_prep = [&]() {
+        const int mt = is_tile / tiles_n, nt = is_tile - mt * tiles_n;
+        ip_w = wb + static_cast<int64_t>(nt) * BN * w_pitch + is_kt * (kLinBK * 2);
+        ip_x = xb + static_cast<int64_t>(mt) * BM * x_pitch + is_kt * (kLinBK * 2);
+        ip_rows_left = p.m - static_cast<int64_t>(mt) * BM;
+        ip_dst = smem + (is_g % NST) * STAGE;
+        ++is_g;
+        if (++is_kt == nk) { is_kt = 0; is_tile += wg_per_xcd; }
+    };
+    auto issue_piece = [&](const int i) {                          // i: compile-time constant at the call sites
+        const unsigned char *src;
+        if (i < BN / 64) {
+            src = ip_w + static_cast<int64_t>(i * 64) * w_pitch + lane_off_w;
+        } else {
+            const int r0 = (i - BN / 64) * 64;
+            src = ip_x + (r0 + wave * 8 < ip_rows_left ? static_cast<int64_t>(r0) * x_pitch : -static_cast<int64_t>(wave * 8) * x_pitch) + lane_off_x;
+        }
+        __builtin_amdgcn_global_load_lds((gbl_ptr_t)(src), (lds_ptr_t)(ip_dst) + (i * 8 + wave) * 1024, 16, 0, 0);
+    };
 
     // fragment read offsets: row * 128 + (((ks << 1) | kh) ^ ((row >> 1) & 7)) * 16, row = base (multiple of 32) + j
     const int sw = (j >> 1) & 7;
@@ -361,7 +386,15 @@ __global__ __launch_bounds__(512, 2) void linear_tn_kernel(const zigma_linear_pa
             wait_vm(NLD * younger + ((ti > 0 && kt < NST - 1 && !(dbg & 0x400)) ? NSTORE : 0));
             __builtin_amdgcn_s_barrier();                       // ... for every wave; and every wave is done with stage (g - 1) % NST
             // (ATT: the load of the next tile's first k-step waits until the attention phase has released the stage it goes to)
-            if (g + NST - 1 < g_total && !(dbg & 0x200) && !(ATT && kt == nk - 1)) issue();
+            const bool do_issue = g + NST - 1 < g_total && !(dbg & 0x200) && !(ATT && kt == nk - 1);
+            // SPREAD (the 256 x 128 tile: three stages, loads two k-steps ahead): the pieces of the batch go out between the MFMAs of
+            // the first two sub-steps instead of as a burst at the top: out_proj 131 -> 120 us, to_out 61 -> 57.  The 256 x 256 tile
+            // (two stages: every cycle of lead counts, 228 instead of 192 registers) measured slower that way (254 vs 241) and keeps the burst.
+            constexpr bool SPREAD = WN_ == 2;
+            constexpr int PPS = (NLD + 1) / 2;                      // pieces per sub-step, sub-steps 0 and 1
+            if (do_issue) {
+                if constexpr (SPREAD) issue_prep(); else issue();
+            }
             const unsigned char *sb = smem + (g % NST) * STAGE;
             // fragments one k-substep ahead of the MFMAs that use them (the LDS latency hides under the previous 8 MFMAs)
             bf16x8 a[2][NB], b[2][MB];
@@ -379,6 +412,12 @@ __global__ __launch_bounds__(512, 2) void linear_tn_kernel(const zigma_linear_pa
 #pragma unroll
             for (int ks = 0; ks < kLinBK / 16; ++ks) {
                 if (ks + 1 < kLinBK / 16) frags(ks + 1, a[(ks + 1) & 1], b[(ks + 1) & 1]);
+                if constexpr (SPREAD) {
+                    if (ks < 2 && do_issue) {
+#pragma unroll
+                        for (int i = ks * PPS; i < (ks + 1) * PPS && i < NLD; ++i) issue_piece(i);
+                    }
+                }
 #pragma unroll
                 for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
