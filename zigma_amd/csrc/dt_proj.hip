@@ -27,7 +27,7 @@ constexpr int kDtTokPerWave = 32, kDtChPerBlock = 64, kDtWaves = 4;
 #endif
 constexpr int kDtIters = ZIGMA_DT_ITERS;
 
-__global__ __launch_bounds__(64 * kDtWaves) void dt_proj_softplus_kernel(const zigma_dtproj_params_t p) {
+__global__ __launch_bounds__(64 * kDtWaves, 5) void dt_proj_softplus_kernel(const zigma_dtproj_params_t p) {
     __shared__ __attribute__((aligned(16))) unsigned char s_tile[kDtWaves * kDtTokPerWave * 144];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
