@@ -341,6 +341,31 @@ int64_t zigma_add_norm_bwd_workspace_bytes(const zigma_norm_bwd_params_t *p);
 int zigma_add_norm_bwd(const zigma_norm_bwd_params_t *p, void *stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Backward of the block's elementwise glue (modulate, gated branch add; reference model_zigma.py:53-54,441-458) in one pass:
+ *   out[r, :]   = dy[r, :] * (s[r / rows_per_batch, :] + s_add)                       (out may be NULL)
+ *   r1[b, c, :] = sum over the 64 rows of chunk c of sample b of dy[r, :] * a[r, :]
+ *   r2[b, c, :] = the same sum of dy[r, :]                                              (r2 may be NULL)
+ * modulate backward: a = x, s = scale, s_add = 1 (out = dx, sum_c r1 = dscale, sum_c r2 = dshift); gated add backward: a = branch,
+ * s = gate, s_add = 0 (out = dbranch, sum_c r1 = dgate).  dy, a, out: (rows, cols) bf16 rows; s: (batch, cols) bf16 rows;
+ * r1, r2: float32 [batch][rows_per_batch / 64][cols], summed over the chunks by the caller (fixed order, no float atomics).
+ * Limits: bf16, cols % 128 == 0, rows_per_batch % 64 == 0, 16-byte aligned rows.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct zigma_glue_bwd_params {
+    int64_t rows;
+    int32_t cols, rows_per_batch;
+    int32_t dtype;           /* ZIGMA_BF16 */
+    int32_t flags;           /* reserved, must be 0 */
+    float s_add;
+    int32_t pad_;
+    int64_t dy_row_stride, a_row_stride, out_row_stride, s_batch_stride;
+    const void *dy, *a, *s;
+    void *out;
+    void *r1, *r2;
+} zigma_glue_bwd_params_t;
+
+int zigma_scale_reduce_bwd(const zigma_glue_bwd_params_t *p, void *stream);
+
+/* ------------------------------------------------------------------------------------------
  * Cross-attention core over a short context:  out = softmax(scale * Q K^T) V  per (sample, head), no mask.
  * Replaces the scaled_dot_product_attention / xformers call of CrossAttention.forward (reference model_zigma.py:113-127;
  * ZigMa: 8 heads x 64, 77 text tokens).  q, out: (batch, seqlen, heads*head_dim) rows; k, v: (batch, n_ctx, heads*head_dim)

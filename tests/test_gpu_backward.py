@@ -314,6 +314,48 @@ def test_mamba_inner_tok_train_with_the_one_pass_conv_x_proj(monkeypatch):
         assert rel_err(N(a), N(b)) < 1e-2
 
 
+@pytest.mark.parametrize("Bsz,L,E", [(2, 64, 128), (3, 192, 640), (16, 1024, 640), (2, 128, 768)])
+def test_glue_backward_kernel_vs_float64(Bsz, L, E):
+    """zigma_scale_reduce_bwd (backward of modulate / gated add in one pass) vs the autograd formulas in float64 on the same bf16
+    operands, including strided operands (a column slice of a wider buffer, a chunk of the adaLN rows)."""
+    from zigma_amd import _lib
+    from zigma_amd.layernorm import glue_bwd_eligible, scale_reduce_bwd
+    g = torch.Generator(device="cpu").manual_seed(L + E)
+    bf = torch.bfloat16
+    dy = torch.randn(Bsz, L, E, generator=g).to(DEV, bf)
+    a = torch.randn(Bsz, L, E + 64, generator=g).to(DEV, bf)[:, :, 64:]
+    s = torch.randn(Bsz, 3 * E, generator=g).to(DEV, bf)[:, E:2 * E]
+    assert glue_bwd_eligible(dy, a, s)
+    out, r1, r2 = scale_reduce_bwd(dy, a, s, s_add=1.0, want_sum=True)
+    assert _lib.last_kernel() == "scale_reduce_bwd"
+    d64, a64, s64 = dy.double(), a.double(), s.double()
+    assert rel_err(N(out), N(d64 * (1 + s64).unsqueeze(1))) < 3e-3
+    assert rel_err(N(r1), N((d64 * a64).sum(1))) < 3e-3 and rel_err(N(r2), N(d64.sum(1))) < 3e-3
+    out2, r1b, none = scale_reduce_bwd(dy, a, s)
+    assert none is None and rel_err(N(out2), N(d64 * s64.unsqueeze(1))) < 3e-3 and torch.equal(r1b, r1)
+    # through the autograd Functions of the block, against plain autograd of the same expressions
+    from zigma_amd.model_zigma import _GatedAddFn, _ModulateFn
+    x = torch.randn(Bsz, L, E, generator=g).to(DEV, bf).requires_grad_(True)
+    sh = torch.randn(Bsz, E, generator=g).to(DEV, bf).requires_grad_(True)
+    sc = torch.randn(Bsz, E, generator=g).to(DEV, bf).requires_grad_(True)
+    w = torch.randn(Bsz, L, E, generator=g).to(DEV, bf)
+    (_ModulateFn.apply(x, sh, sc).float() * w.float()).sum().backward()
+    got = [t.grad.clone() for t in (x, sh, sc)]
+    for t in (x, sh, sc):
+        t.grad = None
+    ((x.double() * (1 + sc.double()).unsqueeze(1) + sh.double().unsqueeze(1)) * w.double()).sum().backward()
+    for a_, t in zip(got, (x, sh, sc)):
+        assert rel_err(N(a_), N(t.grad)) < 4e-3
+    for t in (x, sh, sc):
+        t.grad = None
+    (_GatedAddFn.apply(w, sh, x).float() * dy.float()).sum().backward()
+    got = [t.grad.clone() for t in (sh, x)]
+    for t in (x, sh):
+        t.grad = None
+    ((w.double() + sh.double().unsqueeze(1) * x.double()) * dy.double()).sum().backward()
+    assert rel_err(N(got[0]), N(sh.grad)) < 4e-3 and rel_err(N(got[1]), N(x.grad)) < 4e-3
+
+
 def test_likelihood_sampler_runs_through_hip_backward():
     """Sampler.sample_ode_likelihood needs a vjp through the denoiser at every function evaluation: here it goes through
     LayerNormFn / MambaInnerTokFn (HIP forward + backward).  Checked against a finite-difference divergence probe."""

@@ -116,6 +116,12 @@ class QAttnParams(C.Structure):
                 + [(n, vp) for n in ("x", "w", "k", "vt", "out")])
 
 
+class GlueBwdParams(C.Structure):
+    _fields_ = ([("rows", i64), ("cols", i32), ("rows_per_batch", i32), ("dtype", i32), ("flags", i32), ("s_add", f32), ("pad_", i32)]
+                + [(n, i64) for n in ("dy_row_stride", "a_row_stride", "out_row_stride", "s_batch_stride")]
+                + [(n, vp) for n in ("dy", "a", "s", "out", "r1", "r2")])
+
+
 class XProjParams(C.Structure):
     _fields_ = ([("m", i64), ("n", i32), ("k", i32), ("dtype", i32), ("flags", i32)]
                 + [(n, i64) for n in ("x_row_stride", "w_row_stride", "out_row_stride")] + [(n, vp) for n in ("x", "w", "out")])
@@ -135,7 +141,7 @@ class LinearParams(C.Structure):
                 + [("residual", vp), ("gate", vp), ("res_row_stride", i64), ("gate_batch_stride", i64), ("rows_per_batch", i32), ("pad2_", i32)])
 
 
-EXPORTS = ("zigma_linear_fwd", "zigma_conv_x_proj_fwd", "zigma_q_attn_fwd", "zigma_selective_scan_fwd", "zigma_causal_conv1d_fwd", "zigma_add_norm_fwd", "zigma_dt_proj_softplus_fwd", "zigma_cross_attn_fwd", "zigma_x_proj_fwd", "zigma_selective_scan_bwd",
+EXPORTS = ("zigma_linear_fwd", "zigma_conv_x_proj_fwd", "zigma_q_attn_fwd", "zigma_scale_reduce_bwd", "zigma_selective_scan_fwd", "zigma_causal_conv1d_fwd", "zigma_add_norm_fwd", "zigma_dt_proj_softplus_fwd", "zigma_cross_attn_fwd", "zigma_x_proj_fwd", "zigma_selective_scan_bwd",
            "zigma_selective_scan_bwd_workspace_bytes", "zigma_causal_conv1d_bwd",
            "zigma_causal_conv1d_bwd_workspace_bytes", "zigma_add_norm_bwd", "zigma_add_norm_bwd_workspace_bytes",
            "zigma_strerror",
@@ -157,7 +163,7 @@ def lib():
                          ("zigma_add_norm_fwd", NormParams), ("zigma_dt_proj_softplus_fwd", DtProjParams),
                          ("zigma_selective_scan_bwd", ScanBwdParams), ("zigma_causal_conv1d_bwd", ConvBwdParams),
                          ("zigma_add_norm_bwd", NormBwdParams), ("zigma_cross_attn_fwd", XAttnParams), ("zigma_x_proj_fwd", XProjParams),
-                         ("zigma_linear_fwd", LinearParams), ("zigma_conv_x_proj_fwd", ConvXProjParams), ("zigma_q_attn_fwd", QAttnParams)):
+                         ("zigma_linear_fwd", LinearParams), ("zigma_conv_x_proj_fwd", ConvXProjParams), ("zigma_q_attn_fwd", QAttnParams), ("zigma_scale_reduce_bwd", GlueBwdParams)):
             fn = getattr(L, name)
             fn.argtypes = [C.POINTER(st), vp]
             fn.restype = C.c_int

@@ -204,3 +204,30 @@ def block_norm(x, weight, bias, residual, eps, is_rms, *, residual_in_fp32=True,
         res_out = x2
     rs = lambda t: None if t is None else t.reshape(Bsz, L, E)
     return rs(xe), rs(res_out), rs(y), rs(ym)
+
+
+def glue_bwd_eligible(dy, a, s):
+    """limits of zigma_scale_reduce_bwd: bf16 (B, L, E) rows in one pitch, L % 64 == 0, E % 128 == 0, 16-byte aligned"""
+    if not (dy.is_cuda and dy.dtype == torch.bfloat16 and a.dtype == dy.dtype and s.dtype == dy.dtype and dy.dim() == 3 and a.shape == dy.shape):
+        return False
+    Bsz, L, E = dy.shape
+    ok = lambda t: t.stride(2) == 1 and t.stride(1) % 8 == 0 and t.stride(0) == L * t.stride(1) and t.data_ptr() % 16 == 0
+    return (L % 64 == 0 and E % 128 == 0 and ok(dy) and ok(a) and s.shape == (Bsz, E) and s.stride(1) == 1 and s.stride(0) % 8 == 0
+            and s.data_ptr() % 16 == 0)
+
+
+def scale_reduce_bwd(dy, a, s, s_add=0.0, want_out=True, want_sum=False):
+    """One pass for the backward of the block's elementwise glue (zigma_scale_reduce_bwd):
+        out = dy * (s[:, None] + s_add);  r1 = sum_L dy * a;  r2 = sum_L dy (if want_sum)      ->  (out | None, r1, r2 | None), r in dy.dtype"""
+    dev = _lib.require_device(dy, a, s)
+    Bsz, L, E = dy.shape
+    nch = L // 64
+    out = torch.empty(Bsz, L, E, device=dy.device, dtype=dy.dtype) if want_out else None
+    r1 = torch.empty(Bsz, nch, E, device=dy.device, dtype=torch.float32)
+    r2 = torch.empty(Bsz, nch, E, device=dy.device, dtype=torch.float32) if want_sum else None
+    P = _lib.GlueBwdParams()
+    P.rows, P.cols, P.rows_per_batch, P.dtype, P.flags, P.s_add = Bsz * L, E, L, _lib.dtype_id(dy), 0, float(s_add)
+    P.dy_row_stride, P.a_row_stride, P.out_row_stride, P.s_batch_stride = dy.stride(1), a.stride(1), E, s.stride(0)
+    P.dy, P.a, P.s, P.out, P.r1, P.r2 = _lib.ptr(dy), _lib.ptr(a), _lib.ptr(s), _lib.ptr(out), _lib.ptr(r1), _lib.ptr(r2)
+    _lib.call("zigma_scale_reduce_bwd", P, dev)
+    return out, r1.sum(1).to(dy.dtype), None if r2 is None else r2.sum(1).to(dy.dtype)

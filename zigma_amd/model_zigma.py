@@ -30,7 +30,7 @@ import torch.utils.checkpoint
 from torch import Tensor
 
 from .attention import USE_Q_ATTN, cross_attn, cross_attn_eligible, q_attn, q_attn_eligible, transpose_v
-from .layernorm import RMSNorm, block_norm, layer_norm_fn, rms_norm_fn
+from .layernorm import RMSNorm, block_norm, glue_bwd_eligible, layer_norm_fn, rms_norm_fn, scale_reduce_bwd
 from .linear import TO_Q_OWN, gated_residual_eligible, linear, linear_eligible
 from .mamba_simple import Mamba
 from .scan_paths import hilbert_path, reverse_permut_np, zigzag_path
@@ -52,6 +52,9 @@ class _ModulateFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy):
         x, scale = ctx.saved_tensors
+        if glue_bwd_eligible(dy, x, scale):            # one pass: dx = dy (1 + scale), dshift = sum_L dy, dscale = sum_L dy x
+            dx, dscale, dshift = scale_reduce_bwd(dy, x, scale, s_add=1.0, want_sum=True)
+            return dx, dshift, dscale
         dx = dy * (1 + scale).unsqueeze(1)
         return dx, dy.sum(1), (dy * x).sum(1)
 
@@ -67,6 +70,9 @@ class _GatedAddFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy):
         gate, branch = ctx.saved_tensors
+        if glue_bwd_eligible(dy, branch, gate):        # one pass: dbranch = dy gate, dgate = sum_L dy branch
+            dbranch, dgate, _ = scale_reduce_bwd(dy, branch, gate)
+            return dy, dgate, dbranch
         return dy, (dy * branch).sum(1), dy * gate.unsqueeze(1)
 
 
