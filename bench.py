@@ -19,11 +19,12 @@ roofline  : the fused zigzag selective-scan kernel, timed with HIP events around
             rates (4 plain ops x 2 cycles + 1 v_exp_f32 x 8 cycles per (element, state) wave-instruction group)
             divided by the measured launch time.  `traffic` is NOT measured in this run: it is the per-launch HBM
             byte count of the committed rocprofv3 PMC passes and is labelled with the file it came from.
-cpu_baseline : the reference's OWN CPU path — its unmodified `ZigMa.forward` over `selective_scan_ref` /
-            `causal_conv1d_ref` (oracle/ref_shim.py; from /root/reference, or on the GPU box from oracle/_ref/, the
-            same modules compiled to bytecode by oracle/build_ref.py) — on the host cores, bounded sample (forwards of
-            the same model at B=2), rank 0, N=1 only; `kind: "reference"`.  Falls back to the numpy port (`kind: "port"`)
-            only when neither is importable.
+cpu_baseline : on the host cores, bounded sample (forwards of the same model at B=2), rank 0, N=1 only.  Where
+            /root/reference is mounted (the build container) the reference's OWN CPU path — its unmodified `ZigMa.forward`
+            over `selective_scan_ref` / `causal_conv1d_ref` through oracle/ref_shim.py, `kind: "reference"`; on the GPU box
+            (a Python reference cannot travel) the numpy oracle's forward of the same architecture, `kind: "port"`.
+check       : one forward OUTSIDE the timed region compared with the same model run through the unfused composition
+            (library projections, no epilogue fusion, the two-kernel conv / x_proj): finite + norm-wise distance.
 N > 1 without a launcher: `python bench.py --gpus N` re-executes itself under torch.distributed.run with N ranks.
 """
 import argparse
@@ -112,6 +113,27 @@ def make_inputs(wl, batch, device, seed):
     return x, t, y
 
 
+def check_against_unfused(model, x, t, y, out):
+    """One forward of the SAME model through the unfused composition — library projections (no own MFMA kernel, no gated-add
+    epilogue), the two-kernel conv / x_proj — outside the timed region: the timed path's output must be finite and agree
+    norm-wise (bf16 model: the two compositions round at different points, ~5e-3)."""
+    import zigma_amd.linear as zl
+    import zigma_amd.model_zigma as mz
+    import zigma_amd.selective_scan_interface as ssi
+    saved = (zl.LINEAR_POLICY, mz.FUSE_OUT_PROJ_ADD, ssi.USE_CONV_X_PROJ)
+    zl.LINEAR_POLICY, mz.FUSE_OUT_PROJ_ADD, ssi.USE_CONV_X_PROJ = "off", False, False
+    try:
+        with torch.no_grad():
+            ref = model(x, t, y)
+    finally:
+        zl.LINEAR_POLICY, mz.FUSE_OUT_PROJ_ADD, ssi.USE_CONV_X_PROJ = saved
+    finite = bool(torch.isfinite(out).all())
+    err = float((out.double() - ref.double()).norm() / ref.double().norm())
+    if not finite or not err < 3e-2:
+        raise SystemExit(f"bench.py: the timed path's output fails its check (finite={finite}, rel err vs the unfused composition {err:.3e})")
+    return dict(finite=finite, rel_err_vs_unfused=err, bound=3e-2, checksum=float(out.double().sum()))
+
+
 def _host_threads():
     try:
         return len(os.sched_getaffinity(0))
@@ -170,7 +192,7 @@ def cpu_baseline_reference(wl, seed=0, budget_s=20.0):
         ssi.selective_scan_ref(u, dl, A, Bm, Cm, D, z, db, True)
         sdt = time.perf_counter() - s0
     scan_bytes = B * L * (4 * 4 * Di + 2 * 4 * N) + 4 * Di * (N + 2)          # fp32 I/O
-    src = "/root/reference" if os.path.isdir("/root/reference") else "oracle/_ref (bytecode of the reference, oracle/build_ref.py)"
+    src = "/root/reference"
     return dict(value=B * L / dt, unit="tokens/s", cores=threads, kind="reference", cpu=_cpu_model(),
                 sample=f"{n} forward(s) of the reference's own ZigMa (E=640, depth=18, has_text; selective_scan_ref + "
                        f"causal_conv1d_ref via oracle/ref_shim.py, from {src}) at B={B}, fp32, torch "
@@ -183,11 +205,12 @@ def cpu_baseline_port(wl, seed=0):
     """Fallback: the numpy oracle's forward of the same architecture at B=2 (only when the reference is not importable)."""
     import numpy as np
     from oracle import zigma_oracle as zo
+    threads = min(_host_threads(), 32)                   # BLAS threads of the numpy GEMMs; the recurrence itself is one thread
     try:
-        from threadpoolctl import threadpool_info
-        threads = max([p.get("num_threads", 1) for p in threadpool_info()] + [1])
+        from threadpoolctl import threadpool_limits
+        threadpool_limits(threads)
     except Exception:
-        threads = os.cpu_count() or 1
+        pass
     from zigma_amd.model_zigma import ZigMa
     torch.manual_seed(seed)
     m = ZigMa(device="cpu", dtype=torch.float32, **wl["model"])
@@ -213,8 +236,8 @@ def cpu_baseline(wl, name, limit_s=240):
     """Runs in a CHILD process with a hard time limit (a host with many cores and a small CPU quota can make the torch CPU
     path crawl; the GPU numbers of the line must not depend on it)."""
     import subprocess
-    from oracle import build_ref
-    for kind in (["reference"] if build_ref.available() else []) + ["port"]:
+    from oracle import ref_shim
+    for kind in (["reference"] if ref_shim.available() else []) + ["port"]:
         try:
             r = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-baseline-only", kind, "--workload", name],
                                capture_output=True, text=True, timeout=limit_s,
@@ -295,6 +318,8 @@ def main():
 
     for _ in range(args.warmup):          # scan-event timing only inside the timed region
         step()
+    v_check = step()                      # (every rank: the step holds the gather)
+    check = check_against_unfused(model, x, t, y, v_check) if rank == 0 else None       # outside the timed region
     timer.enabled = not args.no_scan_events
     elapsed = ss.timed_steps(step, args.steps, 0, device, world)
     timer.enabled = False
@@ -328,7 +353,7 @@ def main():
                     config=dict(workload=f"{args.workload}: ZigMa(in_ch=3,img=32,E=640,depth=18,zigzagN8,has_text 77x768), "
                                          f"B={batch}/GPU, bf16, one forward per step",
                                 global_batch=world * batch, seq_len=L, parallelism=f"batch-sharded x{world}"),
-                    roofline=roof)
+                    roofline=roof, check=check)
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(wl, args.workload)
         print(json.dumps(line), flush=True)

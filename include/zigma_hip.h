@@ -27,9 +27,11 @@
 extern "C" {
 #endif
 
-#define ZIGMA_ABI_VERSION 4   /* 2: parameter blocks grew (row tables in the backward, checkpoints, reset_period)
+#define ZIGMA_ABI_VERSION 5   /* 2: parameter blocks grew (row tables in the backward, checkpoints, reset_period)
                                * 3: scan block: `info` out-field, ZIGMA_SCAN_Z_PREACTIVATED flag; zigma_linear_fwd
-                               * 4: zigma_linear_params_t grew (gated residual epilogue); zigma_conv_x_proj_fwd, zigma_q_attn_fwd */
+                               * 4: zigma_linear_params_t grew (gated residual epilogue); zigma_conv_x_proj_fwd, zigma_q_attn_fwd
+                               * 5: pruned — zigma_q_attn_fwd and the dt product of zigma_conv_xproj_params_t removed (measured no faster,
+                               *    archived under tools/experiments/) */
 
 /* zigma_scan_params_t.flags */
 #define ZIGMA_SCAN_Z_PREACTIVATED 2   /* z already holds silu(z) (the in_proj GEMM epilogue applied it): out_z = y * z */
@@ -406,29 +408,6 @@ typedef struct zigma_xproj_params {
 int zigma_x_proj_fwd(const zigma_xproj_params_t *p, void *stream);
 
 /* ------------------------------------------------------------------------------------------
- * q_attn: the query projection AND the attention core of CrossAttention.forward over a short context in one kernel:
- *   q = x @ w^T (bf16);   out[:, h*64:(h+1)*64] = softmax(scale * q_h k_h^T) v_h            per sample and head
- * Replaces to_q + scaled_dot_product_attention of the reference (model_zigma.py:104-127, 8 heads x 64, 77 text tokens, no
- * mask); q never reaches memory.  x: (batch * seqlen, k_dim) rows; w: (heads * 64, k_dim) = to_q.weight; k: (batch, n_ctx,
- * heads * 64) = to_k(text); vt: (batch, heads * 64, vt_keys) = to_v(text) TRANSPOSED per sample, zero beyond n_ctx;
- * out: (batch * seqlen, heads * 64).  Limits: bf16, head_dim 64, heads * 64 % 256 == 0, k_dim % 64 == 0, seqlen % 256 == 0,
- * n_ctx <= 80 <= vt_keys <= 96, vt_keys % 16 == 0, k / vt rows 16-byte aligned.
- * ------------------------------------------------------------------------------------------ */
-typedef struct zigma_qattn_params {
-    int32_t batch, seqlen, n_ctx, heads, head_dim, k_dim;
-    int32_t vt_keys;
-    int32_t dtype;           /* ZIGMA_BF16 */
-    int32_t flags;           /* reserved, must be 0 */
-    float scale;
-    int64_t x_row_stride, w_row_stride, o_row_stride;
-    int64_t k_batch_stride, k_row_stride, vt_batch_stride, vt_row_stride;
-    const void *x, *w, *k, *vt;
-    void *out;
-} zigma_qattn_params_t;
-
-int zigma_q_attn_fwd(const zigma_qattn_params_t *p, void *stream);
-
-/* ------------------------------------------------------------------------------------------
  * conv_x_proj: the depthwise causal conv1d (+ bias, SiLU) over the reordered sequence AND x_proj of its result in one pass:
  *   u[b, k, c]   = silu(conv_bias[c] + sum_{w<4} conv_weight[c, w] * x[b, x_row_index[k - 3 + w], c])     (x[<0] = 0)
  *   out[b*L + k, n] = sum_c u[b, k, c] * w[n, c]
@@ -451,14 +430,6 @@ typedef struct zigma_conv_xproj_params {
     const void *x, *conv_weight, *conv_bias, *w;
     void *u, *out;
     const int32_t *x_row_index;   /* or NULL */
-    /* optional third product (delta != NULL), the dt_proj of zigma_dt_proj_softplus_fwd on this workgroup's own x_dbl rows:
-     *   delta[m, d] = act( sum_{r<dt_rank} out[m, r] * dt_w[d, r] + dt_bias[d] ),  act = softplus iff dt_softplus
-     * dt_w: (dim, dt_rank) bf16 rows; dt_bias: float32 (dim) or NULL; delta: (batch * seqlen, dim) bf16 rows.
-     * dt_rank % 8 == 0, 8 <= dt_rank <= 48. */
-    int32_t dt_rank, dt_softplus;
-    int64_t dt_w_row_stride, delta_row_stride;
-    const void *dt_w, *dt_bias;
-    void *delta;
 } zigma_conv_xproj_params_t;
 
 int zigma_conv_x_proj_fwd(const zigma_conv_xproj_params_t *p, void *stream);

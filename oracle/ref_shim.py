@@ -3,8 +3,8 @@
 TEST INFRASTRUCTURE ONLY.  Used by oracle/make_golden.py (in the build container,
 where /root/reference exists) to generate the golden fixtures under tests/golden/, and by
 bench.py's `cpu_baseline` leg to time the reference's own CPU path.  Nothing in the product
-path imports this file.  On the GPU box there is no /root/reference: the same modules are then
-imported from oracle/_ref/ (bytecode compiled from the reference by oracle/build_ref.py).
+path imports this file.  The reference is Python and cannot travel: on the GPU box there is no
+/root/reference and this module refuses to install (bench.py then times the numpy port, kind "port").
 
 Recipe = SURVEY.md §8c:
   1. stand-in modules `causal_conv1d_cuda` / `selective_scan_cuda` backed by the
@@ -30,9 +30,12 @@ import torch.nn.functional as F
 import os
 
 REF = "/root/reference"
-if not os.path.isdir(REF):            # the GPU box: the reference's hot-path modules as bytecode (oracle/build_ref.py)
-    REF = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_ref")
 _installed = False
+
+
+def available():
+    """True where the reference checkout is mounted (the build container)."""
+    return os.path.isdir(REF)
 
 
 def _mod(name, path=None):
@@ -48,6 +51,8 @@ def install():
     global _installed
     if _installed:
         return
+    if not available():
+        raise RuntimeError("oracle.ref_shim: /root/reference is not mounted here (build container only)")
     _installed = True
     import matplotlib
 

@@ -81,8 +81,75 @@ def test_r2_model_bf16_vs_reference_bf16(name):
     ref_noise = float(g["ref_bf16_vs_fp32"])                      # the reference's bf16 run vs its own fp32 run
     e_fp32, e_bf16 = rel_err(N(out), g["out"]), rel_err(N(out), g["out_bf16"])
     print(f"{name} bf16: vs reference fp32 {e_fp32:.3e} (reference's own bf16: {ref_noise:.3e}), vs reference bf16 {e_bf16:.3e}")
-    assert e_fp32 < 1.25 * ref_noise + 2e-3, (e_fp32, ref_noise)
-    assert e_bf16 < 1.25 * (e_fp32 + ref_noise), (e_bf16, e_fp32, ref_noise)
+    # measured 3.3e-3 ... 5.3e-3 to the reference's own bf16 run; as close to its fp32 result as that run is
+    assert e_bf16 < 1e-2, (e_bf16, e_fp32, ref_noise)
+    assert e_fp32 < 1.1 * ref_noise, (e_fp32, ref_noise)
+
+
+def _trace_counts(trace):
+    """{(entry point, serving kernel): calls}, and the number of projection calls that carried the gated-add epilogue"""
+    counts, gated = {}, 0
+    for fn, kern, P in trace:
+        counts[(fn, kern)] = counts.get((fn, kern), 0) + 1
+        if fn == "zigma_linear_fwd" and P.residual:
+            gated += 1
+    return counts, gated
+
+
+@pytest.mark.parametrize("variant", ["default", "unfused_out_proj", "linear_all", "linear_off"])
+def test_bench_block_path_vs_reference(variant, monkeypatch):
+    """The composition bench.py times: README model, bf16, B = 16 -> 16 384 tokens, so that every size
+    gate of the hot path opens — the one-pass conv + x_proj kernel, out_proj with the block's gated add in its epilogue
+    followed by the want_x=False norm, to_out with its gated add (Block.forward_fused, reference Block.forward
+    model_zigma.py:388-460).  Samples are independent: the two samples of the reference run (r2_readme_b2) sit at batch
+    positions 0 and B-1, the rest is noise; their rows are compared with the reference's fp32 and bf16 outputs.  Which
+    kernels ran is asserted from the call trace.  Variants: the library out_proj + add inside the norm; every projection on
+    the own kernel; none."""
+    import zigma_amd.linear as zl
+    import zigma_amd.model_zigma as mz
+    from zigma_amd import _lib
+    m, g, cfg, y2 = _r2_model("r2_readme_b2", torch.bfloat16)
+    depth = cfg["depth"]
+    Bsz = 16
+    gen = torch.Generator().manual_seed(99)
+    x = torch.randn(Bsz, *g["x"].shape[1:], generator=gen)
+    t = torch.rand(Bsz, generator=gen)
+    y = torch.rand(Bsz, *g["y"].shape[1:], generator=gen)
+    for pos, src in ((0, 0), (Bsz - 1, 1)):
+        x[pos], t[pos], y[pos] = torch.from_numpy(g["x"][src]), float(g["t"][src]), torch.from_numpy(g["y"][src])
+    if variant == "unfused_out_proj":
+        monkeypatch.setattr(mz, "FUSE_OUT_PROJ_ADD", False)
+    elif variant == "linear_all":
+        monkeypatch.setattr(zl, "LINEAR_POLICY", "all")
+    elif variant == "linear_off":
+        monkeypatch.setattr(zl, "LINEAR_POLICY", "off")
+    trace = []
+    monkeypatch.setattr(_lib, "TRACE", trace)
+    with torch.no_grad():
+        out = m(x.to(DEV).bfloat16(), t.to(DEV).bfloat16(), y.to(DEV).bfloat16())
+    monkeypatch.setattr(_lib, "TRACE", None)
+    counts, gated = _trace_counts(trace)
+    n_lin = sum(c for (fn, _), c in counts.items() if fn == "zigma_linear_fwd")
+    assert counts.get(("zigma_conv_x_proj_fwd", "conv_x_proj_mfma"), 0) == depth, counts
+    assert sum(c for (fn, k), c in counts.items() if fn == "zigma_selective_scan_fwd" and k.startswith("scan_tok2")) == depth, counts
+    assert counts.get(("zigma_cross_attn_fwd", "cross_attn_mfma"), 0) == depth, counts
+    if variant == "default":
+        assert gated == 2 * depth, (gated, counts)          # out_proj + to_out, every block
+        assert n_lin >= 2 * depth
+    elif variant == "unfused_out_proj":
+        assert gated == depth, (gated, counts)              # to_out only
+    elif variant == "linear_all":
+        assert gated == 2 * depth and n_lin == 4 * depth, (gated, n_lin, counts)    # in_proj, out_proj, to_q, to_out
+    else:
+        assert n_lin == 0 and gated == 0, counts
+    got = N(out)[[0, Bsz - 1]]
+    ref_noise = float(g["ref_bf16_vs_fp32"])
+    e_fp32, e_bf16 = rel_err(got, g["out"]), rel_err(got, g["out_bf16"])
+    print(f"bench block path [{variant}] B={Bsz}: vs reference fp32 {e_fp32:.3e} (reference's own bf16: {ref_noise:.3e}), "
+          f"vs reference bf16 {e_bf16:.3e}; linear calls {n_lin}, gated {gated}")
+    assert np.isfinite(N(out)).all()
+    assert e_bf16 < 1e-2, (e_bf16, e_fp32, ref_noise)
+    assert e_fp32 < 1.1 * ref_noise, (e_fp32, ref_noise)
 
 
 # ---------------------------------------------------------------------------------------------------

@@ -33,7 +33,7 @@ def test_cabi_exports_every_declared_symbol(libpath):
         assert hasattr(L, name), name
     L.zigma_abi_version.restype = ctypes.c_int
     L.zigma_strerror.restype = ctypes.c_char_p
-    assert L.zigma_abi_version() == 4
+    assert L.zigma_abi_version() == 5
     assert L.zigma_strerror(-2) == b"size out of the supported range"
     from zigma_amd import _lib
     assert set(_lib.EXPORTS) <= declared
@@ -46,7 +46,8 @@ def test_ctypes_structs_match_the_header():
                "zigma_norm_params_t": _lib.NormParams, "zigma_dtproj_params_t": _lib.DtProjParams,
                "zigma_scan_bwd_params_t": _lib.ScanBwdParams, "zigma_conv_bwd_params_t": _lib.ConvBwdParams,
                "zigma_norm_bwd_params_t": _lib.NormBwdParams, "zigma_xattn_params_t": _lib.XAttnParams, "zigma_xproj_params_t": _lib.XProjParams,
-               "zigma_linear_params_t": _lib.LinearParams}
+               "zigma_linear_params_t": _lib.LinearParams, "zigma_conv_xproj_params_t": _lib.ConvXProjParams,
+               "zigma_glue_bwd_params_t": _lib.GlueBwdParams}
     lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "zigma_hip.h"', "int main(void){"]
     for cname, st in structs.items():
         lines.append(f'printf("{cname} %zu\\n", sizeof({cname}));')
@@ -165,6 +166,18 @@ def test_transport_rules_and_fixed_grid_solvers():
     assert got.shape == (7, 2, 2) and np.abs(got.numpy() - ref).max() < 1e-6
     rev = Sampler(tr).sample_ode(sampling_method="euler", num_steps=3, reverse=True)(x0, lambda x, t: torch.ones_like(x))
     assert torch.allclose(rev[-1], x0 - 1)                    # reverse integrates from t=1 down to 0
+    # ... and with the default adaptive solver (data -> noise; decreasing time grid like torchdiffeq accepts): y' = -y(1 + t)
+    # from t = 1 down to 0 is y0 * exp(1.5); bosh3 through the same sign flip; a non-monotonic grid raises
+    for method, tol in (("dopri5", 1e-4), ("bosh3", 2e-3)):
+        rev = Sampler(tr).sample_ode(sampling_method=method, num_steps=5, rtol=1e-5, atol=1e-8, reverse=True)(x0, model)
+        assert rev.shape == (5, 2, 2) and rel_err(rev[-1].numpy(), (x0 * np.exp(1.5)).numpy()) < tol, method
+    fwd = integ.odeint(lambda t, y: -y, x0, torch.tensor([0.0, 0.25, 1.0]), method="dopri5", rtol=1e-6, atol=1e-9)
+    bwd = integ.odeint(lambda t, y: -y, fwd[-1], torch.tensor([1.0, 0.25, 0.0]), method="dopri5", rtol=1e-6, atol=1e-9)
+    assert torch.allclose(bwd[-1], x0, rtol=1e-5) and torch.allclose(bwd[1], fwd[1], rtol=1e-5)
+    with pytest.raises(ValueError):
+        integ.odeint(lambda t, y: -y, x0, torch.tensor([0.0, 0.5, 0.25]), method="dopri5")
+    with pytest.raises(RuntimeError):                         # a NaN from the model stops the solve instead of spinning to max_steps
+        integ.odeint(lambda t, y: y * float("nan"), x0, torch.tensor([0.0, 1.0]), method="dopri5")
     # likelihood ODE on a field with a known divergence: v(x, t) = a x  ->  div = a * dim exactly (Rademacher probes give
     # the exact trace of a diagonal Jacobian), z = x e^{-a}, logp(x) = prior_logp(z) - a * dim
     a = 0.7

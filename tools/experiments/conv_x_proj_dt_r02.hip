@@ -17,9 +17,9 @@
 //   slab (32 x 96 fp32 accumulator per wave, rows beyond n are never stored); u leaves once per stage as full 128-byte lines,
 //   transposed through the wave's own (consumed) input rows.
 //   The products are taken transposed (W_x rows as the MFMA A operand, D[n][position]) so that a lane holds 4 consecutive n of its
-//   position: the x_dbl tile goes through LDS as 8-byte pieces and leaves as 16-byte row pieces.
-//   (dt_proj as a third product of the same launch was built in round 2, bit-identical to the stand-alone kernel and NOT faster
-//   than it — 138.7 vs 71.3 + 64.4 us; archived as tools/experiments/conv_x_proj_dt_r02.hip.)
+//   position: the x_dbl tile goes through LDS as 8-byte pieces and leaves as 16-byte row pieces.  Optionally (delta != NULL) each
+//   wave then runs dt_proj.hip's wave tile on that LDS tile for all d_inner channels: delta = softplus(x_dbl[:, :R] W_dt^T + b) —
+//   bit-identical to the stand-alone kernel and NOT faster than it (138.7 vs 71.3 + 64.4 us), so the host leaves it off.
 // Measured at the headline shape (B=64, L=1024, d_inner=1280, n=72): 72 us against 131 us for conv_tok + x_proj_mfma
 // (tools/conv_xproj_ab.py); loads + MFMA alone 35 us, + conv 64 us, + stores 64 us (probe flags).
 // bf16 only; width 4; bias required; seqlen % 32 == 0; d_inner % 64 == 0; n <= 96, n % 8 == 0.
@@ -84,7 +84,7 @@ __device__ __forceinline__ void wait_vm_n(int n) {
     }
 }
 
-template <int NST, int NW>
+template <int NST, int NW, bool DT>
 __global__ __launch_bounds__(64 * NW) void conv_x_proj_kernel(const zigma_conv_xproj_params_t p) {
     constexpr int kCxWaves = NW, kCxWOff = cx_w_off(NW), kCxCOff = cx_c_off(NW), kCxStage = cx_stage(NW), NWI = (12 + NW - 1) / NW;
     __shared__ __attribute__((aligned(1024))) unsigned char smem[NST * kCxStage];
@@ -245,7 +245,7 @@ __global__ __launch_bounds__(64 * NW) void conv_x_proj_kernel(const zigma_conv_x
     // ---- x_dbl tile of this wave.  The products were taken transposed (W_x rows as the MFMA A operand): D[n][position], a lane holds
     // position j and the outputs n = nb * 32 + (r & 3) + 8 (r >> 2) + 4 kh — 4 consecutive n per register group, one 8-byte piece.
     // The tile goes through LDS (32 rows x 208 B, wave-private; the stage ring is free behind the barrier) and leaves as 16-byte
-    // row pieces.
+    // row pieces; with DT it is also the A operand of the dt_proj product below.
     __builtin_amdgcn_s_barrier();
     constexpr int kPitch = 208;
     const unsigned tile = smem_lds + wave * 8192;
@@ -269,6 +269,60 @@ __global__ __launch_bounds__(64 * NW) void conv_x_proj_kernel(const zigma_conv_x
             for (int i = 0; i < 8; ++i) *reinterpret_cast<u32x4 *>(ob + static_cast<int64_t>(i * 4) * p.out_row_stride * 2) = t[i];
         }
     }
+    if (!DT) return;
+    // ---- delta = softplus(x_dbl[:, :dt_rank] @ W_dt^T + bias) for these 32 positions, all d_inner channels (dt_proj.hip's wave tile:
+    // even / odd channel B fragments, a lane ends up with channels 2j, 2j+1 of a position: packed 4-byte stores, 128 B per row) ------
+    {
+        const int R = p.dt_rank;
+        bf16x8 af[3];
+#pragma unroll
+        for (int s = 0; s < 3; ++s) {
+            const int k0 = s * 16 + kh * 8;
+            u32x4 v;
+            lds_rd(v, tile + j * kPitch + (k0 < R ? k0 : 0) * 2);
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(v));
+            af[s] = __builtin_bit_cast(bf16x8, k0 < R ? v : u32x4{0, 0, 0, 0});
+        }
+        const uint16_t *ww = reinterpret_cast<const uint16_t *>(p.dt_w);
+        const float *bias = reinterpret_cast<const float *>(p.dt_bias);
+        auto wfrags = [&](int d0, bf16x8 (&be)[3], bf16x8 (&bo)[3], float &b_e, float &b_o) {
+            const uint16_t *we = ww + static_cast<int64_t>(d0 + 2 * j) * p.dt_w_row_stride;
+            const uint16_t *wo = we + p.dt_w_row_stride;
+#pragma unroll
+            for (int s = 0; s < 3; ++s) {
+                const int k0 = s * 16 + kh * 8;
+                const uint4 ve = *reinterpret_cast<const uint4 *>(we + (k0 < R ? k0 : 0)), vo = *reinterpret_cast<const uint4 *>(wo + (k0 < R ? k0 : 0));
+                be[s] = __builtin_bit_cast(bf16x8, k0 < R ? ve : make_uint4(0, 0, 0, 0));
+                bo[s] = __builtin_bit_cast(bf16x8, k0 < R ? vo : make_uint4(0, 0, 0, 0));
+            }
+            b_e = bias ? bias[d0 + 2 * j] : 0.f;
+            b_o = bias ? bias[d0 + 2 * j + 1] : 0.f;
+        };
+        bf16x8 be[3], bo[3], be_n[3], bo_n[3];
+        float b_e, b_o, b_en = 0.f, b_on = 0.f;
+        wfrags(0, be, bo, b_e, b_o);
+        uint16_t *orow = reinterpret_cast<uint16_t *>(p.delta) + (m0 + 4 * kh) * p.delta_row_stride + 2 * j;
+#pragma unroll 1
+        for (int d0 = 0; d0 < p.dim; d0 += 64) {
+            if (d0 + 64 < p.dim) wfrags(d0 + 64, be_n, bo_n, b_en, b_on);   // requested before this block's softplus / stores
+            f32x16 ce = {}, co = {};
+#pragma unroll
+            for (int s = 0; s < 3; ++s) {
+                ce = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[s], be[s], ce, 0, 0, 0);
+                co = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[s], bo[s], co, 0, 0, 0);
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int dm = (r & 3) + 8 * (r >> 2);
+                float ve = ce[r] + b_e, vo = co[r] + b_o;
+                if (p.dt_softplus) { ve = softplus20_r16(ve); vo = softplus20_r16(vo); }
+                *reinterpret_cast<uint32_t *>(orow + dm * p.delta_row_stride + d0) = pack_bf2(ve, vo);
+            }
+#pragma unroll
+            for (int s = 0; s < 3; ++s) { be[s] = be_n[s]; bo[s] = bo_n[s]; }
+            b_e = b_en; b_o = b_on;
+        }
+    }
 }
 
 }  // namespace zigma
@@ -285,6 +339,13 @@ extern "C" int zigma_conv_x_proj_fwd(const zigma_conv_xproj_params_t *pp, void *
     if (!p.x || !p.conv_weight || !p.conv_bias || !p.w || !p.u || !p.out) return ZIGMA_ERR_NULL;
     if (p.dtype != ZIGMA_BF16) return ZIGMA_ERR_DTYPE;
     if (p.n > 96 || p.n % 8 != 0 || p.dim % kCxBK != 0 || p.seqlen % kCxTok != 0) return ZIGMA_ERR_SHAPE;
+    if (p.delta) {                       // optional third product: delta = softplus(x_dbl[:, :dt_rank] @ dt_w^T + dt_bias)
+        if (!p.dt_w) return ZIGMA_ERR_NULL;
+        if (p.dt_rank < 8 || p.dt_rank > 48 || p.dt_rank % 8 != 0 || p.dt_rank > p.n) return ZIGMA_ERR_SHAPE;
+        if (p.dt_w_row_stride % 8 != 0 || p.delta_row_stride % 2 != 0 || reinterpret_cast<uintptr_t>(p.dt_w) % 16 != 0 ||
+            reinterpret_cast<uintptr_t>(p.delta) % 4 != 0)
+            return ZIGMA_ERR_STRIDE;
+    }
     if (p.out_row_stride % 8 != 0 || reinterpret_cast<uintptr_t>(p.out) % 16 != 0) return ZIGMA_ERR_STRIDE;
     const int64_t m = static_cast<int64_t>(p.batch) * p.seqlen;
     if (m % (kCxTok * 8) != 0) return ZIGMA_ERR_SHAPE;       // (either workgroup size)
@@ -297,7 +358,10 @@ extern "C" int zigma_conv_x_proj_fwd(const zigma_conv_xproj_params_t *pp, void *
     // while the other waits for its loads (measured 72 us; 8 waves in lockstep 75 us; a third stage does not pay, the second
     // workgroup does its job).  flags: 1 = three stages, 2 = eight-wave workgroups; probes (wrong results): 4 = no u stores,
     // 8 = no conv arithmetic.
-#define ZIGMA_CX(S_, W_) hipLaunchKernelGGL((conv_x_proj_kernel<S_, W_>), grid, block, 0, stream, p);
+    const bool dt = p.delta != nullptr;
+#define ZIGMA_CX(S_, W_)                                                                                        \
+    if (dt) hipLaunchKernelGGL((conv_x_proj_kernel<S_, W_, true>), grid, block, 0, stream, p);                  \
+    else hipLaunchKernelGGL((conv_x_proj_kernel<S_, W_, false>), grid, block, 0, stream, p);
     if (p.flags & 2) {
         const dim3 grid(static_cast<unsigned>(m / (kCxTok * 8))), block(64 * 8);
         if (p.flags & 1) { ZIGMA_CX(3, 8) } else { ZIGMA_CX(2, 8) }
@@ -306,6 +370,6 @@ extern "C" int zigma_conv_x_proj_fwd(const zigma_conv_xproj_params_t *pp, void *
         if (p.flags & 1) { ZIGMA_CX(3, 4) } else { ZIGMA_CX(2, 4) }
     }
 #undef ZIGMA_CX
-    set_last_kernel("conv_x_proj_mfma");
+    set_last_kernel(dt ? "conv_x_proj_dt_mfma" : "conv_x_proj_mfma");
     return check_launch();
 }

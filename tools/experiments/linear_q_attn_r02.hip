@@ -125,6 +125,130 @@ __device__ __forceinline__ void linear_epilogue(const f32x16 (&acc)[NB][MB], uns
     }
 }
 
+// ---- cross-attention over a SHORT context on the accumulators of the to_q projection (zigma_q_attn_fwd) -----------------------
+// A wave tile is 64 features = ONE head for its MB * 32 tokens, and the accumulator layout D[feature][token] is already the
+// B-operand layout of S^T = K Q^T up to the order of the contraction index: a lane (token j, k-half kh) holds, in registers
+// 8a .. 8a+7 of block nb, the dims nb*32 + 16a + {4kh .. 4kh+3, 8 + 4kh .. 8 + 4kh+3} — so the K fragments are fetched in that
+// order (two 8-byte pieces per lane from the K row) and Q never leaves the registers: rounded to bf16 (the reference's q is a
+// bf16 tensor), S^T (keys in registers, a token per lane: softmax = a register reduction + one cross-half swap), P rounded to
+// bf16, O^T = V^T P^T with the same trick on the keys (V^T rows are contiguous over the padded keys), O^T / rowsum written
+// back into the accumulators, which have exactly the layout the projection epilogue stores.  K_h / V_h^T (2 x 10 KB per
+// (sample, head)) come straight from L2 / L1 as MFMA fragments.
+struct qattn_extra_t {
+    const uint16_t *k, *vt;
+    int64_t k_batch_stride, k_row_stride, vt_batch_stride, vt_row_stride;
+    int32_t n_ctx, seqlen;
+    float scale_log2e;
+};
+
+__device__ __forceinline__ bf16x8 pack8(const float (&v)[8]) {
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    u32x4 r;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) r[i] = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{v[2 * i], v[2 * i + 1]}, bf16x2));
+    return __builtin_bit_cast(bf16x8, r);
+}
+__device__ __forceinline__ float cross_half_max(float x) {
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+__device__ __forceinline__ float cross_half_sum(float x) {
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+// LDS staging of the tile's K_h (rows of 64 dims, pitch 136 B) and V_h^T (rows of 80 keys, pitch 168 B): the pitches make the
+// 8-byte fragment reads of 32 consecutive rows conflict-free.  Straight from global the fragments cost one memory request per
+// row and instruction (32 lines per wave instruction): 117 us for the whole kernel against 85 for the two it replaces.
+constexpr int kAtKPitch = 136, kAtKHead = 80 * kAtKPitch, kAtVPitch = 168, kAtVHead = 64 * kAtVPitch, kAtMaxCtx = 80;
+
+// two 8-byte pieces of a bf16 LDS row: elements [e0 + 4 kh, +4) and [e0 + 8 + 4 kh, +4)
+__device__ __forceinline__ bf16x8 frag_8_8(const unsigned char *row, int e0, int kh) {
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    const uint2 lo = *reinterpret_cast<const uint2 *>(row + (e0 + 4 * kh) * 2), hi = *reinterpret_cast<const uint2 *>(row + (e0 + 8 + 4 * kh) * 2);
+    return __builtin_bit_cast(bf16x8, u32x4{lo.x, lo.y, hi.x, hi.y});
+}
+
+template <int MB>
+__device__ __forceinline__ void attn_in_place(f32x16 (&acc)[2][MB], const unsigned char *k_lds, const unsigned char *vt_lds, const int n_ctx,
+                                              const float c, const int lane) {
+    const int j = lane & 31, kh = lane >> 5;
+#pragma unroll                     // (a run-time mb would index the accumulators dynamically: they would live in scratch)
+    for (int mb = 0; mb < MB; ++mb) {
+        bf16x8 qf[2][2];
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+            for (int a = 0; a < 2; ++a) {
+                float v[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) v[i] = acc[nb][mb][8 * a + i];
+                qf[nb][a] = pack8(v);
+            }
+        f32x16 S[3];
+#pragma unroll
+        for (int kb = 0; kb < 3; ++kb) {
+            S[kb] = f32x16{};
+            if (kb * 32 < n_ctx) {                                                       // wave-uniform
+                const int key = kb * 32 + j;
+                const unsigned char *row = k_lds + (key < n_ctx ? key : n_ctx - 1) * kAtKPitch;
+                bf16x8 kf[2][2];                                                           // all four fragments in flight before the MFMAs
+#pragma unroll
+                for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+                    for (int a = 0; a < 2; ++a) kf[nb][a] = frag_8_8(row, nb * 32 + 16 * a, kh);
+#pragma unroll
+                for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+                    for (int a = 0; a < 2; ++a) S[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[nb][a], qf[nb][a], S[kb], 0, 0, 0);
+            }
+        }
+        // softmax over the keys of this lane's token: keys kb*32 + (r & 3) + 8 (r >> 2) + 4 kh in register r of block kb
+        float m = -INFINITY;
+#pragma unroll
+        for (int kb = 0; kb < 3; ++kb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                if (kb * 32 + 32 > n_ctx) {                                              // wave-uniform: only a partial block needs the mask
+                    const int key = kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+                    S[kb][r] = key < n_ctx ? S[kb][r] : -INFINITY;
+                }
+                m = fmaxf(m, S[kb][r]);
+            }
+        m = cross_half_max(m);
+        float l = 0.f;
+#pragma unroll
+        for (int kb = 0; kb < 3; ++kb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                S[kb][r] = fast_exp2((S[kb][r] - m) * c);
+                l += S[kb][r];
+            }
+        l = cross_half_sum(l);
+        const float inv = fast_rcp(l);
+        f32x16 O[2] = {f32x16{}, f32x16{}};
+#pragma unroll
+        for (int kb = 0; kb < 3; ++kb)
+#pragma unroll
+            for (int a = 0; a < 2; ++a) {
+                if (kb * 32 + 16 * a < n_ctx) {                                          // wave-uniform: keys beyond carry P = 0
+                    const bf16x8 v0 = frag_8_8(vt_lds + j * kAtVPitch, kb * 32 + 16 * a, kh), v1 = frag_8_8(vt_lds + (32 + j) * kAtVPitch, kb * 32 + 16 * a, kh);
+                    float v[8];
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) v[i] = S[kb][8 * a + i];
+                    const bf16x8 pf = pack8(v);
+                    O[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v0, pf, O[0], 0, 0, 0);
+                    O[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v1, pf, O[1], 0, 0, 0);
+                }
+            }
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[nb][mb][r] = O[nb][r] * inv;
+    }
+}
+
 // s_waitcnt vmcnt(n) for the handful of counts the pipeline uses (the instruction takes an immediate)
 __device__ __forceinline__ void wait_vm(int n) {
     switch (n) {
@@ -146,8 +270,9 @@ __device__ __forceinline__ void wait_vm(int n) {
 // was issued after the batch this k-step needs": the younger load batch (NST == 3) and, during the first NST - 1 k-steps
 // after an epilogue, that epilogue's stores — the store acknowledgements are never waited for on the critical path
 // (__syncthreads() would drain them: measured ~2 us per tile).
-template <int WN_, int NST, bool HAS_BIAS, bool RES = false>
-__global__ __launch_bounds__(512, 2) void linear_tn_kernel(const zigma_linear_params_t p, const int tiles_m, const int tiles_n) {
+template <int WN_, int NST, bool HAS_BIAS, bool ATT = false, bool RES = false>
+__global__ __launch_bounds__(512, 2) void linear_tn_kernel(const zigma_linear_params_t p, const int tiles_m, const int tiles_n,
+                                                           const qattn_extra_t ex = qattn_extra_t{}) {
     constexpr int BM = kLinBM, BN = 64 * WN_, WM_ = 8 / WN_, MB = BM / WM_ / 32, NB = 2;
     constexpr int ROWS = BN + BM, STAGE = ROWS * 128;            // bytes per stage: W rows first, then token rows
     constexpr int NLD = ROWS / 64;                                 // direct-to-LDS loads per wave per stage (8 rows each)
@@ -260,7 +385,8 @@ __global__ __launch_bounds__(512, 2) void linear_tn_kernel(const zigma_linear_pa
             const int younger = (g_total - 1 - g) < (NST - 2) ? (g_total - 1 - g) : (NST - 2);
             wait_vm(NLD * younger + ((ti > 0 && kt < NST - 1 && !(dbg & 0x400)) ? NSTORE : 0));
             __builtin_amdgcn_s_barrier();                       // ... for every wave; and every wave is done with stage (g - 1) % NST
-            const bool do_issue = g + NST - 1 < g_total && !(dbg & 0x200);
+            // (ATT: the load of the next tile's first k-step waits until the attention phase has released the stage it goes to)
+            const bool do_issue = g + NST - 1 < g_total && !(dbg & 0x200) && !(ATT && kt == nk - 1);
             // SPREAD (the 256 x 128 tile: three stages, loads two k-steps ahead): the pieces of the batch go out between the MFMAs of
             // the first two sub-steps instead of as a burst at the top: out_proj 131 -> 120 us, to_out 61 -> 57.  The 256 x 256 tile
             // (two stages: every cycle of lead counts, 228 instead of 192 registers) measured slower that way (254 vs 241) and keeps the burst.
@@ -323,6 +449,42 @@ __global__ __launch_bounds__(512, 2) void linear_tn_kernel(const zigma_linear_pa
             const int64_t m_tile = static_cast<int64_t>(mt) * BM + wm * (BM / WM_);           // first token of this wave's tile
             const int64_t rows_here = p.m - m_tile;                                            // tokens of it that exist
             const int64_t o_pitch = p.out_row_stride * 2;
+            if constexpr (ATT) {
+                // seqlen % 256 == 0: the tile lies inside one sample; its 256 features are 4 heads, wave column wn = head.
+                // Both stages are free now (the next tile's first load was held back): K of the 4 heads + V^T of heads 0, 1 go to
+                // the stage that load will fill, V^T of heads 2, 3 above the epilogue scratch of the other one.
+                static_assert(WN_ == 4 && NST == 2, "the attention phase is laid out for the 256 x 256 tile with two stages");
+                unsigned char *stA = smem + ((g - 1) % NST) * STAGE, *stB = smem + (g % NST) * STAGE;
+                const int64_t bsm = (static_cast<int64_t>(mt) * BM) / ex.seqlen;
+                const uint16_t *kg = ex.k + bsm * ex.k_batch_stride + nt * BN;
+                const uint16_t *vg = ex.vt + bsm * ex.vt_batch_stride + static_cast<int64_t>(nt) * BN * ex.vt_row_stride;
+                typedef unsigned u4 __attribute__((ext_vector_type(4)));
+                for (int pc = tid; pc < ex.n_ctx * 32; pc += 512) {                       // K: 32 16-byte pieces per key (4 heads x 8)
+                    const int key = pc >> 5, w = pc & 31;
+                    const u4 v = *reinterpret_cast<const u4 *>(kg + static_cast<int64_t>(key) * ex.k_row_stride + w * 8);
+                    const unsigned dst = static_cast<unsigned>(reinterpret_cast<uintptr_t>((lds_ptr_t)(stB))) + (w >> 3) * kAtKHead + key * kAtKPitch + (w & 7) * 16;
+                    asm volatile("ds_write_b64 %0, %1" ::"v"(dst), "v"(__builtin_shufflevector(v, v, 0, 1)) : "memory");
+                    asm volatile("ds_write_b64 %0, %1 offset:8" ::"v"(dst), "v"(__builtin_shufflevector(v, v, 2, 3)) : "memory");
+                }
+                for (int pc = tid; pc < 256 * 16; pc += 512) {                            // V^T: 10 16-byte pieces (80 keys) per (head, dim) row
+                    const int row = pc >> 4, w = pc & 15;
+                    if (w < 10) {
+                        const u4 v = *reinterpret_cast<const u4 *>(vg + static_cast<int64_t>(row) * ex.vt_row_stride + w * 8);
+                        const int hh = row >> 6;
+                        unsigned char *base = hh < 2 ? stB + 4 * kAtKHead + hh * kAtVHead : stA + 32768 + (hh - 2) * kAtVHead;
+                        const unsigned dst = static_cast<unsigned>(reinterpret_cast<uintptr_t>((lds_ptr_t)(base))) + (row & 63) * kAtVPitch + w * 16;
+                        asm volatile("ds_write_b64 %0, %1" ::"v"(dst), "v"(__builtin_shufflevector(v, v, 0, 1)) : "memory");
+                        asm volatile("ds_write_b64 %0, %1 offset:8" ::"v"(dst), "v"(__builtin_shufflevector(v, v, 2, 3)) : "memory");
+                    }
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                attn_in_place<MB>(acc, stB + wn * kAtKHead, wn < 2 ? stB + 4 * kAtKHead + wn * kAtVHead : stA + 32768 + (wn - 2) * kAtVHead, ex.n_ctx,
+                                  ex.scale_log2e, lane);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();                                             // every wave is done with K / V^T
+                if (g < g_total && !(dbg & 0x200)) issue();                               // the load held back above
+            }
             // rows as buffer descriptor (base = the wave tile's first row and first column, extent = its valid rows): stores of
             // tokens beyond m fall outside the extent and are dropped by the hardware
             const rsrc_t o_rs = make_rsrc(reinterpret_cast<unsigned char *>(p.out) + m_tile * o_pitch + (nt * BN + wn * 64) * 2,
@@ -383,15 +545,58 @@ extern "C" int zigma_linear_fwd(const zigma_linear_params_t *pp, void *stream_) 
     if (n_tiles > 0x7fffffff) return ZIGMA_ERR_SHAPE;
     int grid = 256;                                  // one persistent workgroup per CU; multiples of 8 keep the XCD map
     if (n_tiles < grid) grid = static_cast<int>((n_tiles + 7) / 8 * 8);
-#define ZIGMA_LIN(W_, S_, B_) hipLaunchKernelGGL((linear_tn_kernel<W_, S_, B_>), dim3(grid), dim3(512), 0, stream, p, tiles_m, tiles_n)
+#define ZIGMA_LIN(W_, S_, B_) hipLaunchKernelGGL((linear_tn_kernel<W_, S_, B_>), dim3(grid), dim3(512), 0, stream, p, tiles_m, tiles_n, qattn_extra_t{})
     if (wide) { if (p.bias) ZIGMA_LIN(4, 2, true); else ZIGMA_LIN(4, 2, false); }
     else if (p.flags & 0x800) { if (p.bias) ZIGMA_LIN(2, 2, true); else ZIGMA_LIN(2, 2, false); }      // 0x800: two stages (probe)
     else if (p.residual) {
-        if (p.bias) hipLaunchKernelGGL((linear_tn_kernel<2, 3, true, true>), dim3(grid), dim3(512), 0, stream, p, tiles_m, tiles_n);
-        else hipLaunchKernelGGL((linear_tn_kernel<2, 3, false, true>), dim3(grid), dim3(512), 0, stream, p, tiles_m, tiles_n);
+        if (p.bias) hipLaunchKernelGGL((linear_tn_kernel<2, 3, true, false, true>), dim3(grid), dim3(512), 0, stream, p, tiles_m, tiles_n, qattn_extra_t{});
+        else hipLaunchKernelGGL((linear_tn_kernel<2, 3, false, false, true>), dim3(grid), dim3(512), 0, stream, p, tiles_m, tiles_n, qattn_extra_t{});
     }
     else { if (p.bias) ZIGMA_LIN(2, 3, true); else ZIGMA_LIN(2, 3, false); }
 #undef ZIGMA_LIN
     set_last_kernel(wide ? "linear_tn_256x256" : "linear_tn_256x128");
+    return check_launch();
+}
+
+extern "C" int zigma_q_attn_fwd(const zigma_qattn_params_t *pp, void *stream_) {
+    if (!pp) return ZIGMA_ERR_NULL;
+    (void)hipGetLastError();
+    const zigma_qattn_params_t &q = *pp;
+    if (q.batch < 0 || q.seqlen < 0 || q.heads < 1 || q.n_ctx < 1 || q.k_dim < 1) return ZIGMA_ERR_SHAPE;
+    if (q.flags != 0) return ZIGMA_ERR_UNSUPPORTED;
+    if (q.batch == 0 || q.seqlen == 0) return ZIGMA_OK;
+    if (!q.x || !q.w || !q.k || !q.vt || !q.out) return ZIGMA_ERR_NULL;
+    if (q.dtype != ZIGMA_BF16) return ZIGMA_ERR_DTYPE;
+    const int n = q.heads * 64;
+    if (q.head_dim != 64 || n % 256 != 0 || q.k_dim % kLinBK != 0 || q.seqlen % 256 != 0 || q.n_ctx > kAtMaxCtx || q.vt_keys < q.n_ctx ||
+        q.vt_keys % 16 != 0 || q.vt_keys > 96)
+        return ZIGMA_ERR_SHAPE;
+    const int64_t m = static_cast<int64_t>(q.batch) * q.seqlen;
+    if (m * q.x_row_stride * 2 > 0x7fffffff || static_cast<int64_t>(n) * q.w_row_stride * 2 > 0x7fffffff || 256 * q.o_row_stride * 2 > 0x7fffffff)
+        return ZIGMA_ERR_SHAPE;
+    auto al = [](const void *ptr, int a) { return reinterpret_cast<uintptr_t>(ptr) % a == 0; };
+    if (q.x_row_stride % 8 != 0 || q.w_row_stride % 8 != 0 || q.o_row_stride % 4 != 0 || q.k_row_stride % 4 != 0 || q.k_batch_stride % 4 != 0 ||
+        q.vt_row_stride % 4 != 0 || q.vt_batch_stride % 4 != 0 || q.vt_row_stride < q.vt_keys + 0 || !al(q.x, 16) || !al(q.w, 16) || !al(q.out, 8) ||
+        !al(q.k, 8) || !al(q.vt, 8))
+        return ZIGMA_ERR_STRIDE;
+    if (q.vt_keys < kAtMaxCtx) return ZIGMA_ERR_SHAPE;          // 80 keys of every V^T row are staged (zeros beyond n_ctx)
+    if (q.vt_row_stride % 8 != 0 || q.vt_batch_stride % 8 != 0 || q.k_row_stride % 8 != 0 || q.k_batch_stride % 8 != 0 || !al(q.k, 16) || !al(q.vt, 16))
+        return ZIGMA_ERR_STRIDE;                                  // 16-byte staging loads
+    zigma_linear_params_t p{};
+    p.m = m; p.n = n; p.k = q.k_dim; p.dtype = q.dtype; p.flags = 0; p.silu_from_col = n;
+    p.x_row_stride = q.x_row_stride; p.w_row_stride = q.w_row_stride; p.out_row_stride = q.o_row_stride;
+    p.x = q.x; p.w = q.w; p.bias = nullptr; p.out = q.out;
+    qattn_extra_t ex;
+    ex.k = reinterpret_cast<const uint16_t *>(q.k); ex.vt = reinterpret_cast<const uint16_t *>(q.vt);
+    ex.k_batch_stride = q.k_batch_stride; ex.k_row_stride = q.k_row_stride;
+    ex.vt_batch_stride = q.vt_batch_stride; ex.vt_row_stride = q.vt_row_stride;
+    ex.n_ctx = q.n_ctx; ex.seqlen = q.seqlen; ex.scale_log2e = q.scale * 1.4426950408889634f;
+    const int tiles_m = static_cast<int>(m / kLinBM), tiles_n = n / 256;
+    const int64_t n_tiles = static_cast<int64_t>(tiles_m) * tiles_n;
+    if (n_tiles > 0x7fffffff) return ZIGMA_ERR_SHAPE;
+    int grid = 256;
+    if (n_tiles < grid) grid = static_cast<int>((n_tiles + 7) / 8 * 8);
+    hipLaunchKernelGGL((linear_tn_kernel<4, 2, false, true>), dim3(grid), dim3(512), 0, static_cast<hipStream_t>(stream_), p, tiles_m, tiles_n, ex);
+    set_last_kernel("q_attn_256x256");
     return check_launch();
 }

@@ -35,6 +35,9 @@ def main():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--class-label", type=int, default=None, help="class-conditional models: the label to sample")
     ap.add_argument("--graph", action="store_true")
+    ap.add_argument("--decode", default="none", choices=["none", "standin"],
+                    help="standin: decode -> uint8 on the device inside the timed path (zigma_amd.postprocess; a 4->3 channel 8x "
+                         "upsampling stand-in for the reference's third-party VAE, sample_acc.py:363-392) and gather the pixels")
     ap.add_argument("--out", default=None)
     args = ap.parse_args()
 
@@ -66,16 +69,26 @@ def main():
     if args.graph:
         z0 = torch.zeros((nb,) + shape, device=device)
         model_fn = GraphedForward(model, z0, torch.zeros(nb, device=device), kw.get("y"))
+    dec = None
+    if args.decode == "standin":
+        from zigma_amd import postprocess as pp
+        dec = pp.StandInDecoder(latent_channels=cfg["in_channels"], device=device)
     outs, t0 = [], time.perf_counter()
     with torch.no_grad():
         for i in range(-(-args.num_samples // args.batch)):
-            outs.append(ss.sample_sharded(sample_fn, model_fn, shape, args.batch, args.seed + i * world, device, **kw).cpu())
+            if dec is None:
+                outs.append(ss.sample_sharded(sample_fn, model_fn, shape, args.batch, args.seed + i * world, device, **kw).cpu())
+            else:       # this rank's latents -> images -> uint8 -> ONE gather of the pixels (sample_acc.py:362-392,435)
+                g = torch.Generator(device="cpu").manual_seed(ss.rank_seed(args.seed + i * world, rank))
+                z = torch.randn((nb,) + tuple(shape), generator=g).to(device)
+                outs.append(pp.finish_samples(sample_fn(z, model_fn, **kw)[-1], dec, is_video=bool(frames), world=world).cpu())
     ss.fence(device, world)
     dt = time.perf_counter() - t0
     if rank == 0:
         x = torch.cat(outs)[:args.num_samples]
         print(json.dumps(dict(samples=int(x.shape[0]), shape=list(x.shape[1:]), seconds=round(dt, 3),
-                              samples_per_s=round(x.shape[0] / dt, 2), world=world, finite=bool(torch.isfinite(x).all()))))
+                              samples_per_s=round(x.shape[0] / dt, 2), world=world, decode=args.decode,
+                              finite=bool(torch.isfinite(x.float()).all()))))
         if args.out:
             torch.save(x, args.out)
     if world > 1:

@@ -109,13 +109,6 @@ class XAttnParams(C.Structure):
                 + [(n, vp) for n in ("q", "k", "v", "out")])
 
 
-class QAttnParams(C.Structure):
-    _fields_ = ([(n, i32) for n in ("batch", "seqlen", "n_ctx", "heads", "head_dim", "k_dim", "vt_keys", "dtype", "flags")] + [("scale", f32)]
-                + [(n, i64) for n in ("x_row_stride", "w_row_stride", "o_row_stride", "k_batch_stride", "k_row_stride", "vt_batch_stride",
-                                      "vt_row_stride")]
-                + [(n, vp) for n in ("x", "w", "k", "vt", "out")])
-
-
 class GlueBwdParams(C.Structure):
     _fields_ = ([("rows", i64), ("cols", i32), ("rows_per_batch", i32), ("dtype", i32), ("flags", i32), ("s_add", f32), ("pad_", i32)]
                 + [(n, i64) for n in ("dy_row_stride", "a_row_stride", "out_row_stride", "s_batch_stride")]
@@ -130,9 +123,7 @@ class XProjParams(C.Structure):
 class ConvXProjParams(C.Structure):
     _fields_ = ([(n, i32) for n in ("batch", "seqlen", "dim", "n", "dtype", "flags")]
                 + [(n, i64) for n in ("x_batch_stride", "x_l_stride", "u_batch_stride", "u_l_stride", "w_row_stride", "out_row_stride")]
-                + [(n, vp) for n in ("x", "conv_weight", "conv_bias", "w", "u", "out", "x_row_index")]
-                + [("dt_rank", i32), ("dt_softplus", i32), ("dt_w_row_stride", i64), ("delta_row_stride", i64)]
-                + [(n, vp) for n in ("dt_w", "dt_bias", "delta")])
+                + [(n, vp) for n in ("x", "conv_weight", "conv_bias", "w", "u", "out", "x_row_index")])
 
 
 class LinearParams(C.Structure):
@@ -141,7 +132,7 @@ class LinearParams(C.Structure):
                 + [("residual", vp), ("gate", vp), ("res_row_stride", i64), ("gate_batch_stride", i64), ("rows_per_batch", i32), ("pad2_", i32)])
 
 
-EXPORTS = ("zigma_linear_fwd", "zigma_conv_x_proj_fwd", "zigma_q_attn_fwd", "zigma_scale_reduce_bwd", "zigma_selective_scan_fwd", "zigma_causal_conv1d_fwd", "zigma_add_norm_fwd", "zigma_dt_proj_softplus_fwd", "zigma_cross_attn_fwd", "zigma_x_proj_fwd", "zigma_selective_scan_bwd",
+EXPORTS = ("zigma_linear_fwd", "zigma_conv_x_proj_fwd", "zigma_scale_reduce_bwd", "zigma_selective_scan_fwd", "zigma_causal_conv1d_fwd", "zigma_add_norm_fwd", "zigma_dt_proj_softplus_fwd", "zigma_cross_attn_fwd", "zigma_x_proj_fwd", "zigma_selective_scan_bwd",
            "zigma_selective_scan_bwd_workspace_bytes", "zigma_causal_conv1d_bwd",
            "zigma_causal_conv1d_bwd_workspace_bytes", "zigma_add_norm_bwd", "zigma_add_norm_bwd_workspace_bytes",
            "zigma_strerror",
@@ -163,7 +154,7 @@ def lib():
                          ("zigma_add_norm_fwd", NormParams), ("zigma_dt_proj_softplus_fwd", DtProjParams),
                          ("zigma_selective_scan_bwd", ScanBwdParams), ("zigma_causal_conv1d_bwd", ConvBwdParams),
                          ("zigma_add_norm_bwd", NormBwdParams), ("zigma_cross_attn_fwd", XAttnParams), ("zigma_x_proj_fwd", XProjParams),
-                         ("zigma_linear_fwd", LinearParams), ("zigma_conv_x_proj_fwd", ConvXProjParams), ("zigma_q_attn_fwd", QAttnParams), ("zigma_scale_reduce_bwd", GlueBwdParams)):
+                         ("zigma_linear_fwd", LinearParams), ("zigma_conv_x_proj_fwd", ConvXProjParams), ("zigma_scale_reduce_bwd", GlueBwdParams)):
             fn = getattr(L, name)
             fn.argtypes = [C.POINTER(st), vp]
             fn.restype = C.c_int
@@ -177,7 +168,7 @@ def lib():
         L.zigma_strerror.restype = C.c_char_p
         L.zigma_abi_version.restype = C.c_int
         L.zigma_last_kernel.restype = C.c_char_p
-        if L.zigma_abi_version() != 4:
+        if L.zigma_abi_version() != 5:
             raise RuntimeError("zigma_amd: libzigma_hip.so ABI version mismatch")
         _lib = L
     return _lib
@@ -221,6 +212,9 @@ def workspace(fn_name, params, device):
     return ws
 
 
+TRACE = None        # tests / tools: set to a list to receive (entry point, kernel that served it, parameter block) per call
+
+
 def call(fn_name, params, device):
     L = lib()
     with torch.cuda.device(device):
@@ -228,3 +222,5 @@ def call(fn_name, params, device):
         rc = getattr(L, fn_name)(C.byref(params), C.c_void_p(stream))
     if rc != 0:
         raise RuntimeError(f"{fn_name}: {L.zigma_strerror(rc).decode()} (status {rc})")
+    if TRACE is not None:
+        TRACE.append((fn_name, L.zigma_last_kernel().decode(), params))

@@ -6,11 +6,10 @@ and adds `block_norm`, the ZigMa-block form with the gated branch add and adaLN 
 """
 import torch
 
-import os
 
 from . import _lib
 
-NORM_FLAGS = 1 if os.environ.get("ZIGMA_NORM_ONE_ROW") == "1" else 0      # 1: one row per wave even where four fit (A/B probe)
+NORM_FLAGS = 0      # 1: one row per wave even where four fit (A/B probe; tools set it directly)
 
 
 def _norm_call(x2, weight, bias, residual2, eps, is_rms, residual_dtype, *, rows_per_batch=None, branch=None,
@@ -207,12 +206,12 @@ def block_norm(x, weight, bias, residual, eps, is_rms, *, residual_in_fp32=True,
 
 
 def glue_bwd_eligible(dy, a, s):
-    """limits of zigma_scale_reduce_bwd: bf16 (B, L, E) rows in one pitch, L % 64 == 0, E % 128 == 0, 16-byte aligned"""
+    """limits of zigma_scale_reduce_bwd: bf16 (B, L, E) rows in one pitch, L % 64 == 0, E % 128 == 0, E <= 8192, 16-byte aligned"""
     if not (dy.is_cuda and dy.dtype == torch.bfloat16 and a.dtype == dy.dtype and s.dtype == dy.dtype and dy.dim() == 3 and a.shape == dy.shape):
         return False
     Bsz, L, E = dy.shape
     ok = lambda t: t.stride(2) == 1 and t.stride(1) % 8 == 0 and t.stride(0) == L * t.stride(1) and t.data_ptr() % 16 == 0
-    return (L % 64 == 0 and E % 128 == 0 and ok(dy) and ok(a) and s.shape == (Bsz, E) and s.stride(1) == 1 and s.stride(0) % 8 == 0
+    return (L % 64 == 0 and E % 128 == 0 and E <= 8192 and ok(dy) and ok(a) and s.shape == (Bsz, E) and s.stride(1) == 1 and s.stride(0) % 8 == 0
             and s.data_ptr() % 16 == 0)
 
 

@@ -33,8 +33,8 @@ def linear_eligible(x, weight, bias=None, fused_epilogue=False, prefer_own=False
     n, k = weight.shape
     if k % 64 or n % 128 or x.shape[-1] != k or x.stride(-1) != 1 or weight.stride(1) != 1:
         return False
-    if bias is not None and (bias.dtype != torch.bfloat16 or bias.stride(0) != 1):
-        return False
+    if bias is not None and (bias.dtype != torch.bfloat16 or bias.stride(0) != 1 or n > 4096 or bias.data_ptr() % 4):
+        return False                                     # (the kernel stages the bias vector in 8 KB of LDS)
     m = x.numel() // k
     if m % 8 or m == 0:
         return False

@@ -18,7 +18,6 @@ What is different underneath (sampling / eval forward):
     in the input dtype, so an fp32 ODE state can drive a bf16 model.
 """
 import math
-import os
 from functools import partial
 from typing import Optional
 
@@ -29,9 +28,9 @@ import torch.nn.functional as F
 import torch.utils.checkpoint
 from torch import Tensor
 
-from .attention import USE_Q_ATTN, cross_attn, cross_attn_eligible, q_attn, q_attn_eligible, transpose_v
+from .attention import cross_attn, cross_attn_eligible
 from .layernorm import RMSNorm, block_norm, glue_bwd_eligible, layer_norm_fn, rms_norm_fn, scale_reduce_bwd
-from .linear import TO_Q_OWN, gated_residual_eligible, linear, linear_eligible
+from .linear import gated_residual_eligible, linear, linear_eligible
 from .mamba_simple import Mamba
 from .scan_paths import hilbert_path, reverse_permut_np, zigzag_path
 
@@ -137,14 +136,7 @@ class CrossAttention(nn.Module):
         Bsz, L, _ = x.shape
         H = self.heads
         k, v = kv[:2] if kv is not None else (self.to_k(text), self.to_v(text))
-        if USE_Q_ATTN and not torch.is_grad_enabled() and q_attn_eligible(x, self.to_q.weight, k, H):
-            # HIP kernels: to_q AND the attention core in one pass (q stays in the accumulators), to_out on the MFMA projection kernel
-            vt = kv[2] if kv is not None and len(kv) > 2 else transpose_v(v)
-            return self._proj_out(q_attn(x, self.to_q.weight, k, vt, H, self.scale), residual, gate)
-        if TO_Q_OWN and linear_eligible(x, self.to_q.weight, None, prefer_own=True):
-            q = linear(x, self.to_q.weight, None)          # the whole attention branch on hand-written kernels (+ 5 us against the library)
-        else:
-            q = self._proj(x, self.to_q)
+        q = self._proj(x, self.to_q)
         if not torch.is_grad_enabled() and cross_attn_eligible(q, k, v, H):
             # HIP kernels: attention core in one pass (K/V of the head in LDS), to_out on the MFMA projection kernel
             return self._proj_out(cross_attn(q, k, v, H, self.scale), residual, gate)
@@ -262,8 +254,8 @@ class Pending:
 # out_proj on the own projection kernel WITH the block's gated add `n + gate_msa * mixer(.)` in its epilogue, instead of the library
 # GEMM + the add inside the following norm kernel.  Per block (profiles/r02_b_bench_kernel_stats.csv vs r02_d_*): out_proj 127 -> 150 us,
 # pre-attention add + norm 68 -> 47, and with to_out's gated add: to_out 63 -> 78, pre-mixer add + norm 119 -> 102 — time moves from
-# the HBM-bound norm kernels into the projection epilogues, the forward is 0.1-0.3 % faster.  ZIGMA_OUT_PROJ_FUSED=0: library out_proj.
-FUSE_OUT_PROJ_ADD = os.environ.get("ZIGMA_OUT_PROJ_FUSED", "1") != "0"
+# the HBM-bound norm kernels into the projection epilogues, the forward is 0.1-0.3 % faster.
+FUSE_OUT_PROJ_ADD = True       # (module-level knob for tests / tools; no environment switch)
 
 
 class Block(nn.Module):
@@ -631,11 +623,6 @@ class ZigMa(nn.Module):
             inner = blocks[0].msa.to_k.weight.shape[0]
             kv_all = F.linear(text, Wkv).view(text.shape[0], text.shape[1], n, 2, inner)
             kvs = [(kv_all[:, :, i, 0], kv_all[:, :, i, 1]) for i in range(n)]
-            if USE_Q_ATTN and not torch.is_grad_enabled() and text.shape[1] <= 80 and kv_all.dtype == torch.bfloat16 and kv_all.is_cuda:
-                # V^T of every layer in one copy (rows contiguous over the zero-padded keys): what the one-kernel to_q + attention reads
-                vt_all = torch.zeros(text.shape[0], n, inner, 96, device=kv_all.device, dtype=kv_all.dtype)
-                vt_all[:, :, :, :text.shape[1]] = kv_all[:, :, :, 1].permute(0, 2, 3, 1)
-                kvs = [kvs[i] + (vt_all[:, i],) for i in range(n)]
         return mods, kvs
 
     def ckpt_wrapper(self, module):

@@ -32,6 +32,23 @@ def decode_latents(latents, decode=None, latent_scale=LATENT_SCALE, is_video=Fal
     return torch.stack([decode(latents[i] / latent_scale) for i in range(len(latents))], dim=1)
 
 
+class StandInDecoder(torch.nn.Module):
+    """A fixed, seeded latent -> image map with the SHAPE behaviour of the reference's VAE decoder (4 latent channels -> 3 image
+    channels, 8x upsampling: `vae.decode(z).sample`, sample_acc.py:365) for tests and end-to-end timing where the third-party
+    `diffusers.AutoencoderKL` is absent: an 8x8 transposed conv (stride 8) + tanh.  NOT a VAE — results are not images."""
+
+    def __init__(self, latent_channels=4, image_channels=3, up=8, seed=0, device=None, dtype=torch.float32):
+        super().__init__()
+        g = torch.Generator().manual_seed(seed)
+        w = torch.randn(latent_channels, image_channels, up, up, generator=g) * (0.5 / latent_channels ** 0.5)
+        self.up = up
+        self.register_buffer("weight", w.to(device=device, dtype=dtype))
+        self.register_buffer("bias", (torch.randn(image_channels, generator=g) * 0.1).to(device=device, dtype=dtype))
+
+    def forward(self, z):
+        return torch.tanh(torch.nn.functional.conv_transpose2d(z.to(self.weight.dtype), self.weight, self.bias, stride=self.up))
+
+
 def finish_samples(latents, decode=None, latent_scale=LATENT_SCALE, is_video=False, world=None):
     """decode -> uint8 -> gather over ranks (dim 0, rank order).  Returns a uint8 tensor on the latents' device."""
     with torch.no_grad():

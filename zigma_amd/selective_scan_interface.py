@@ -26,14 +26,10 @@ from .causal_conv1d_interface import causal_conv1d_raw, conv_bwd_tok
 
 
 SPLIT_SMALL_BATCH = True     # tools/latency_probe.py flips this to measure the effect of the small-batch sequence split
-# conv + SiLU + x_proj in one kernel (u written once, never read back): ZIGMA_CONV_XPROJ=0 pins the two separate kernels
-USE_CONV_X_PROJ = os.environ.get("ZIGMA_CONV_XPROJ", "1") != "0"
-CONV_X_PROJ_MIN_POSITIONS = int(os.environ.get("ZIGMA_CONV_XPROJ_MIN", "16384"))   # below: too few workgroups (128 positions each)
-# ... and dt_proj + softplus as a third product of that launch: built, bit-identical to the stand-alone kernel, NOT faster
-# (138.7 us against 71.3 + 64 = 135.7: inside one workgroup the phases add up, and the VALU / store-bound dt phase runs at the
-# 2 waves per SIMD of the 200-register main loop instead of its own 4) — off unless ZIGMA_CONV_XPROJ_DT=1
-USE_CONV_X_PROJ_DT = os.environ.get("ZIGMA_CONV_XPROJ_DT", "0") == "1"
-DT_PROJ_FLAGS = 1 if os.environ.get("ZIGMA_DT_PROJ_NARROW_STORES") == "1" else 0     # 1: four-byte stores (A/B probe)
+# module-level knobs for the A/B tools and tests (tools/, tests/ set them directly; no environment switches)
+USE_CONV_X_PROJ = True               # conv + SiLU + x_proj in one kernel (u written once, never read back); False: the two kernels
+CONV_X_PROJ_MIN_POSITIONS = 16384    # below: too few workgroups (128 positions each)
+DT_PROJ_FLAGS = 0                    # 1: four-byte stores (A/B probe of dt_proj.hip)
 USE_X_PROJ_KERNEL = True      # own MFMA kernel for the skinny x_proj instead of the library GEMM (same speed stand-alone)
 SPLIT_MAX_WGS = 200          # ... and sweeps this: split when batch * d_inner / 64 is at most this many workgroups (tools/split_threshold_probe.py)
 
@@ -219,14 +215,12 @@ def conv_x_proj_eligible(x_half, conv_w, conv_b, x_proj_weight, perm, reset_peri
             and (perm is None or (perm.dtype == torch.int32 and perm.is_contiguous())))
 
 
-def conv_x_proj(x_half, conv_w, conv_b, x_proj_weight, perm=None, _flags=0, dt_weight=None, dt_bias=None, dt_softplus=True):
+def conv_x_proj(x_half, conv_w, conv_b, x_proj_weight, perm=None, _flags=0):
     """u = silu(causal_conv1d(x_half[:, perm])) and x_dbl = u @ x_proj_weight.T in one pass over x (zigma_conv_x_proj_fwd).
     x_half: (B, L, d_inner) bf16 view with contiguous channels (the first half of the in_proj output, as is); conv_w: (d_inner, 4);
     returns u (B, L, d_inner) in SCAN order and x_dbl (B, L, n).  Replaces causal_conv1d_fn + F.linear of reference
-    selective_scan_interface.py:307-322.  With dt_weight (d_inner, dt_rank) the same launch also produces
-    delta = softplus(x_dbl[..., :dt_rank] @ dt_weight.T + dt_bias) (selective_scan_interface.py:323 + the scan's softplus) and
-    returns (u, x_dbl, delta)."""
-    dev = _lib.require_device(x_half, conv_w, conv_b, x_proj_weight, perm, dt_weight, dt_bias)
+    selective_scan_interface.py:307-322."""
+    dev = _lib.require_device(x_half, conv_w, conv_b, x_proj_weight, perm)
     Bsz, L, Di = x_half.shape
     n = x_proj_weight.shape[0]
     u = torch.empty(Bsz, L, Di, device=x_half.device, dtype=x_half.dtype)
@@ -238,25 +232,8 @@ def conv_x_proj(x_half, conv_w, conv_b, x_proj_weight, perm=None, _flags=0, dt_w
     P.w_row_stride, P.out_row_stride = x_proj_weight.stride(0), n
     P.x, P.conv_weight, P.conv_bias, P.w = _lib.ptr(x_half), _lib.ptr(conv_w), _lib.ptr(conv_b), _lib.ptr(x_proj_weight)
     P.u, P.out, P.x_row_index = _lib.ptr(u), _lib.ptr(x_dbl), _lib.ptr(perm)
-    delta = None
-    if dt_weight is not None:
-        if dt_weight.dtype != x_half.dtype or dt_weight.shape[0] != Di or dt_weight.stride(1) != 1:
-            raise RuntimeError("dt_weight must be (d_inner, dt_rank) rows of the activation dtype")
-        if dt_bias is not None and (dt_bias.dtype != torch.float32 or not dt_bias.is_contiguous()):
-            raise RuntimeError("dt_bias must be contiguous float32")
-        delta = torch.empty(Bsz, L, Di, device=x_half.device, dtype=x_half.dtype)
-        P.dt_rank, P.dt_softplus = dt_weight.shape[1], int(bool(dt_softplus))
-        P.dt_w_row_stride, P.delta_row_stride = dt_weight.stride(0), Di
-        P.dt_w, P.dt_bias, P.delta = _lib.ptr(dt_weight), _lib.ptr(dt_bias), _lib.ptr(delta)
     _lib.call("zigma_conv_x_proj_fwd", P, dev)
-    return (u, x_dbl) if delta is None else (u, x_dbl, delta)
-
-
-def dt_proj_weight_ok(weight, dt_rank, n, bias):
-    """limits of the dt_proj product inside zigma_conv_x_proj_fwd: bf16 (d_inner, dt_rank) rows, dt_rank % 8 == 0, 8..48, float32 bias"""
-    return (weight.dtype == torch.bfloat16 and weight.shape[1] == dt_rank and 8 <= dt_rank <= 48 and dt_rank % 8 == 0 and dt_rank <= n
-            and weight.stride(1) == 1 and weight.stride(0) % 8 == 0 and weight.data_ptr() % 16 == 0
-            and (bias is None or (bias.dtype == torch.float32 and bias.is_contiguous())))
+    return u, x_dbl
 
 
 def dt_proj_eligible(x_dbl, dt_rank, weight):
@@ -544,14 +521,8 @@ def mamba_inner_tok(xz, conv1d_weight, conv1d_bias, x_proj_weight, delta_proj_we
     N = A.shape[1]
     w = conv1d_weight.reshape(Di, -1)
     x_half, z_half = xz[:, :, :Di], xz[:, :, Di:]
-    delta = None
     if USE_CONV_X_PROJ and conv_x_proj_eligible(x_half, w, conv1d_bias, x_proj_weight, perm, reset_period):
-        if USE_CONV_X_PROJ_DT and delta_softplus and dt_proj_weight_ok(delta_proj_weight, R, x_proj_weight.shape[0], delta_bias):
-            # one pass: read x, write u (scan order), x_dbl and delta = softplus(dt_proj(x_dbl) + bias)
-            u, x_dbl, delta = conv_x_proj(x_half, w, conv1d_bias, x_proj_weight, perm, dt_weight=delta_proj_weight, dt_bias=delta_bias)
-            delta_bias, delta_softplus = None, False
-        else:
-            u, x_dbl = conv_x_proj(x_half, w, conv1d_bias, x_proj_weight, perm)   # one pass: read x, write u (scan order) and x_dbl
+        u, x_dbl = conv_x_proj(x_half, w, conv1d_bias, x_proj_weight, perm)   # one pass: read x, write u (scan order) and x_dbl
     else:
         # depthwise causal conv + SiLU over the reordered sequence; u is in SCAN order
         u = torch.empty(Bsz, L, Di, device=xz.device, dtype=xz.dtype)
@@ -561,10 +532,7 @@ def mamba_inner_tok(xz, conv1d_weight, conv1d_bias, x_proj_weight, delta_proj_we
             x_dbl = x_proj(u, x_proj_weight)                             # (B, L, R + 2N)   read-bound MFMA kernel
         else:
             x_dbl = F.linear(u, x_proj_weight)                           # (B, L, R + 2N)   GEMM
-    fused_dt = delta is None and delta_softplus and dt_proj_eligible(x_dbl, R, delta_proj_weight)
-    if delta is not None:
-        pass
-    elif fused_dt:   # K = dt_rank GEMM + bias + softplus in one write-bound MFMA kernel; scan skips its softplus
+    if delta_softplus and dt_proj_eligible(x_dbl, R, delta_proj_weight):   # K = dt_rank GEMM + bias + softplus in one write-bound MFMA kernel; scan skips its softplus
         delta = dt_proj_softplus(x_dbl, R, delta_proj_weight, delta_bias, True)
         delta_bias, delta_softplus = None, False
     else:

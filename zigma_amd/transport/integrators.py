@@ -10,6 +10,8 @@ restatement of the same controller (oracle/zigma_oracle.py, tests/test_host_cpu.
 Solver state and arithmetic stay in the dtype of `x` (keep the latents fp32; the model casts at its own
 boundary), time points in float32 like the reference (`th.linspace`).
 """
+import math
+
 import torch as th
 
 # -- Butcher tableaux ---------------------------------------------------------------------------------
@@ -97,8 +99,12 @@ def _adaptive(tab, f, y0, ts, rtol, atol, norm=rms_norm, max_steps=100000):
     dev = y0.device
     f64 = dict(device=dev, dtype=th.float64)
     ts_host = [float(v) for v in ts.tolist()]                        # output times are host data to begin with
+    if len(ts_host) > 1 and ts_host[0] > ts_host[-1]:
+        # decreasing time grid (Sampler.sample_ode(reverse=True): data -> noise): integrate y'(s) = -f(-s, y) on s = -t, as
+        # torchdiffeq does (odeint's `_check_inputs` flips the sign of t and of the function)
+        return _adaptive(tab, lambda s, y: -f(-s, y), y0, -ts, rtol, atol, norm=norm, max_steps=max_steps)
     if any(t1 <= t0 for t0, t1 in zip(ts_host, ts_host[1:])):
-        raise ValueError("t must be strictly increasing")
+        raise ValueError("t must be strictly increasing or strictly decreasing")
     call = lambda t, y: f(t.to(th.float32), y)
     t0 = th.tensor(ts_host[0], **f64)
     f0 = call(t0, y0)
@@ -143,8 +149,14 @@ def _adaptive(tab, f, y0, ts, rtol, atol, norm=rms_norm, max_steps=100000):
         dfac = th.where(ratio < 1, one, fifth)
         factor = th.where(ratio == 0, ten, th.minimum(ten, th.maximum(0.9 / ratio.clamp_min(1e-300) ** (1.0 / order), dfac)))
         t1 = t0 + dt
-        flag, t1_host = th.stack([accept.double(), t1]).tolist()      # the ONE host read of this step
+        flag, t1_host, ratio_host = th.stack([accept.double(), t1, ratio]).tolist()      # the ONE host read of this step
         st.host_reads += 1
+        # torchdiffeq asserts on a non-finite state / step underflow; without this a NaN from the model (accept is then always
+        # False and dt becomes NaN) would spin to max_steps at 6 model evaluations + one host read per step
+        if ratio_host != ratio_host or not math.isfinite(t1_host):
+            raise RuntimeError("adaptive ODE solver: non-finite error estimate or time (the model returned NaN / inf?)")
+        if not t1_host > t0_host:
+            raise RuntimeError("adaptive ODE solver: step size underflow")
         if flag:
             st.accepted += 1
             f_new = ks[-1] if tab["fsal"] else call(t1, y1)
