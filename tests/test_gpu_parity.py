@@ -753,6 +753,38 @@ def test_linear_kernel_vs_float64(M, K, N, bias, act, monkeypatch):
         assert torch.equal(wide[:, 64:64 + N], y) and float(wide[:, :64].abs().max()) == 0 and float(wide[:, 64 + N:].abs().max()) == 0
 
 
+@pytest.mark.parametrize("M,K,N", [(65536, 640, 2560), (65536, 640, 512), (16384, 192, 4096), (65536, 1280, 256), (32768, 512, 1024)])
+def test_linear4w_kernel(M, K, N, monkeypatch):
+    """The one-wave-per-SIMD projection kernel (csrc/linear4w.hip, generated main loop): served shapes report it, every output of
+    sampled rows against float64 on the same bf16 operands, bit-identity with the 8-wave kernel (same MFMA, same accumulation
+    order), run-to-run identity (a synchronisation bug shows as a flicker), and a strided output."""
+    from zigma_amd import _lib
+    import zigma_amd.linear as zl
+    from zigma_amd.linear import linear, linear_eligible, routes_to_4w
+    g = torch.Generator(device="cpu").manual_seed(M + N + K)
+    x = torch.randn(M, K, generator=g).to(DEV, torch.bfloat16)
+    w = (torch.randn(N, K, generator=g) * K ** -0.5).to(DEV, torch.bfloat16)
+    assert routes_to_4w(M, N, K) and linear_eligible(x, w, None)          # default policy
+    y = linear(x, w)
+    assert _lib.last_kernel() == "linear4w_256x256" and y.shape == (M, N)
+    rows = torch.randint(0, M, (1024,), generator=g).to(DEV)
+    rows[:4] = torch.tensor([0, 255, 256, M - 1], device=DEV)
+    ref = x[rows].double() @ w.double().T
+    got = y[rows].double()
+    assert float((got - ref).norm() / ref.norm()) < 2.5e-3
+    assert torch.allclose(got, ref, rtol=1.6e-2, atol=1e-2)
+    y8 = linear(x, w, _probe_flags=0x2000)
+    assert _lib.last_kernel().startswith("linear_tn_")
+    assert torch.equal(y, y8)
+    for _ in range(4):
+        assert torch.equal(linear(x, w), y)
+    if N <= 1024:
+        wide = torch.zeros(M, N + 256, device=DEV, dtype=torch.bfloat16)
+        linear(x, w, out=wide[:, 128:128 + N])
+        assert _lib.last_kernel() == "linear4w_256x256"
+        assert torch.equal(wide[:, 128:128 + N], y) and float(wide[:, :128].abs().max()) == 0 and float(wide[:, 128 + N:].abs().max()) == 0
+
+
 @pytest.mark.parametrize("Bsz,L,K,Nn,bias", [(2, 256, 512, 640, True), (3, 512, 128, 128, False), (16, 1024, 512, 640, True)])
 def test_linear_gated_residual_epilogue(Bsz, L, K, Nn, bias, monkeypatch):
     """out = residual + gate[b] * bf16(x @ W^T + bias) in the projection kernel's epilogue (the block's gated branch add) vs the

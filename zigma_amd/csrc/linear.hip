@@ -347,6 +347,10 @@ __global__ __launch_bounds__(512, 2) void linear_tn_kernel(const zigma_linear_pa
     }
 }
 
+// csrc/linear4w.hip: the one-wave-per-SIMD kernel for the wide, epilogue-free projections (in_proj, to_q)
+bool linear4w_eligible(const zigma_linear_params_t &p);
+int launch_linear4w(const zigma_linear_params_t &p, hipStream_t stream);
+
 }  // namespace zigma
 
 using namespace zigma;
@@ -356,7 +360,7 @@ extern "C" int zigma_linear_fwd(const zigma_linear_params_t *pp, void *stream_) 
     (void)hipGetLastError();
     const zigma_linear_params_t &p = *pp;
     if (p.m < 0 || p.n < 1 || p.k < 1) return ZIGMA_ERR_SHAPE;
-    if (p.flags & ~0x1f00) return ZIGMA_ERR_UNSUPPORTED;     // 0x100 ... 0x1000: timing / A-B probes (tools/linear_probe.py)
+    if (p.flags & ~0x3f00) return ZIGMA_ERR_UNSUPPORTED;     // 0x100 ... 0x1000: timing / A-B probes (tools/linear_probe.py); 0x2000: the 8-wave kernel
     if (p.m == 0) return ZIGMA_OK;
     if (!p.x || !p.w || !p.out) return ZIGMA_ERR_NULL;
     if (p.dtype != ZIGMA_BF16) return ZIGMA_ERR_DTYPE;
@@ -369,6 +373,7 @@ extern "C" int zigma_linear_fwd(const zigma_linear_params_t *pp, void *stream_) 
         (reinterpret_cast<uintptr_t>(p.x) | reinterpret_cast<uintptr_t>(p.w)) % 16 != 0 || reinterpret_cast<uintptr_t>(p.out) % 8 != 0)
         return ZIGMA_ERR_STRIDE;
     hipStream_t stream = static_cast<hipStream_t>(stream_);
+    if (linear4w_eligible(p)) return launch_linear4w(p, stream);        // (needs flags == 0: any probe flag pins the 8-wave kernel)
     const int tiles_m = static_cast<int>((p.m + kLinBM - 1) / kLinBM);
     if (p.residual) {                     // gated residual epilogue: the 256 x 128 tile kernel
         if (!p.gate || p.rows_per_batch < 1 || p.rows_per_batch % 256 != 0 || p.m % p.rows_per_batch != 0) return ZIGMA_ERR_SHAPE;

@@ -17,8 +17,9 @@ import os
 LINEAR_POLICY = os.environ.get("ZIGMA_LINEAR", "auto")
 
 
-# to_q on the own kernel under "auto": + 9 us per block inside the forward (18.77 vs 18.60 ms, same box) — off unless ZIGMA_TO_Q_OWN=1
-TO_Q_OWN = os.environ.get("ZIGMA_TO_Q_OWN", "0") == "1"
+def routes_to_4w(m, n, k, bias=None):
+    """shapes zigma_linear_fwd serves with the one-wave-per-SIMD kernel (csrc/linear4w.hip): the wide epilogue-free projections"""
+    return bias is None and m % 256 == 0 and n % 256 == 0 and k % 64 == 0 and k >= 192 and (m // 256) * (n // 256) >= 256
 
 
 def linear_eligible(x, weight, bias=None, fused_epilogue=False, prefer_own=False):
@@ -26,8 +27,9 @@ def linear_eligible(x, weight, bias=None, fused_epilogue=False, prefer_own=False
     rows, no autograd"""
     if not (LINEAR_POLICY != "off" and x.is_cuda and x.dtype == torch.bfloat16 and weight.dtype == torch.bfloat16):
         return False
-    if LINEAR_POLICY == "auto" and bias is None and not fused_epilogue and not prefer_own:   # (an epilogue the library cannot fuse is a
-        return False                                                                           #  reason too)
+    m_, (n_, k_) = x.numel() // max(x.shape[-1], 1), weight.shape
+    if LINEAR_POLICY == "auto" and bias is None and not fused_epilogue and not prefer_own and not routes_to_4w(m_, n_, k_):
+        return False        # (auto: projections with an epilogue the library cannot fuse, and the wide ones the 4-wave kernel takes)
     if torch.is_grad_enabled() and (x.requires_grad or weight.requires_grad or (bias is not None and bias.requires_grad)):
         return False
     n, k = weight.shape
