@@ -33,7 +33,8 @@ def build(force=False, verbose=True, sources=None, lib=None, extra_flags=()):
     library that already matches its sources must not be rebuilt there)."""
     sources = sources or SOURCES
     lib = lib or LIB
-    os.makedirs(OBJ, exist_ok=True)
+    obj_dir = OBJ if lib == LIB else OBJ + "_" + os.path.splitext(os.path.basename(lib))[0]      # (A/B libraries of tools/ keep their own objects)
+    os.makedirs(obj_dir, exist_ok=True)
     os.makedirs(os.path.dirname(lib), exist_ok=True)
     headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".h", ".inc"))]
     headers.append(os.path.join(ROOT, "include", "zigma_hip.h"))
@@ -52,7 +53,7 @@ def build(force=False, verbose=True, sources=None, lib=None, extra_flags=()):
     objs, jobs = [], []
     for src in sources:
         s_path = os.path.join(CSRC, src)
-        o_path = os.path.join(OBJ, src.replace(".hip", ".o"))
+        o_path = os.path.join(obj_dir, src.replace(".hip", ".o"))
         o_stamp = o_path + ".srchash"
         o_want = _digest([s_path] + headers, extra=list(FLAGS) + list(extra_flags))
         objs.append(o_path)

@@ -94,6 +94,9 @@ def acc(nb, mb):
 # ------------------------------------------------------------------------------------------------------------------
 # emitter with issue log: counted waits are derived from it
 # ------------------------------------------------------------------------------------------------------------------
+OPTS = set()       # probe variants (timing only, results wrong): "nomfma", "noreads", "noglds", "nostore"
+
+
 class Emit:
     def __init__(self):
         self.lines = []
@@ -102,11 +105,16 @@ class Emit:
         self.vm_own = 0         # vector-memory ops issued in this block so far
         self.n_inst = 0
         self.mfma_at = {}       # accumulator base -> instruction index of the last MFMA that wrote it
+        self.in_prologue = False
 
     def raw(self, text):
         self.lines.append(text)
 
     def ins(self, text):
+        if "laxvm" in OPTS and text.startswith("s_waitcnt vmcnt("):
+            text = "s_waitcnt vmcnt(63)" + text[text.index(")") + 1:]
+        if "noepi" in OPTS and (text.startswith("v_cvt_pk") or (text.startswith("ds_read_b128 v[1") and int(text.split("[")[1].split(":")[0]) >= RM.ROW)):
+            return
         self.lines.append(text)
         self.n_inst += 1
         if text.startswith("s_nop"):
@@ -118,11 +126,15 @@ class Emit:
     # --- LDS ---------------------------------------------------------------------------------------------
     def ds_read(self, dst, addr_v, off):
         assert 0 <= off < 65536
+        if "noreads" in OPTS and dst < RM.ROW:
+            return
         self.ins(f"ds_read_b128 {v(dst, 4)}, {v(addr_v)} offset:{off}")
         self.lgkm.append(set(range(dst, dst + 4)))
 
     def ds_write_acc(self, addr_v, areg, off):
         assert 0 <= off < 65536
+        if "noepi" in OPTS:
+            return
         blk = areg // 16 * 16
         if blk in self.mfma_at:                       # wait states between the MFMA that wrote the block and this read of it
             gap = self.n_inst - self.mfma_at[blk] - 1
@@ -158,6 +170,9 @@ class Emit:
 
     def glds_issue(self):
         voff_v, sbase = self.pending_glds
+        if "noglds" in OPTS and not self.in_prologue:
+            self.vm_after_glds = 0
+            return
         if self.lines[-1].startswith("s_add_u32 m0"):          # one wait state between the write of M0 and its consumer
             self.ins("s_nop 0")
         self.ins(f"global_load_lds_dwordx4 {v(voff_v)}, {s(sbase, 2)}")
@@ -165,19 +180,25 @@ class Emit:
         self.vm_after_glds = 0
 
     def store(self, data, soff, imm):
+        if "nostore" in OPTS:
+            return
         self.ins(f"buffer_store_dwordx4 {v(data, 4)}, {v(RM.STOFF)}, {s(RM.S_RS, 4)}, {s(soff)} offen offset:{imm}")
         self.vm_own += 1
         if self.vm_after_glds is not None:
             self.vm_after_glds += 1
 
     def mfma(self, c, fa, fb, zero=False):
+        if "nomfma" in OPTS:
+            return
         src = "0" if zero else a(c, 16)
         self.ins(f"v_mfma_f32_32x32x16_bf16 {a(c, 16)}, {v(fa, 4)}, {v(fb, 4)}, {src}")
         self.mfma_at[c] = self.n_inst - 1
 
 
-def interleave(e, mfmas, fillers, first_gap=0):
-    """MFMAs with the filler thunks spread evenly over the gaps behind them (nothing in the first `first_gap` gaps)"""
+def interleave(e, mfmas, fillers, first_gap=0, cap=None):
+    """MFMAs with the filler thunks in the gaps behind them (nothing in the first `first_gap` gaps).  cap = None: spread evenly;
+    cap = n: FRONT-LOADED, n per gap until they run out (loads go first so that their latency runs under the remaining MFMAs;
+    whatever is left after the last MFMA is emitted behind it)."""
     n = len(mfmas)
     gaps = max(n - first_gap, 1)
     done = 0
@@ -185,7 +206,12 @@ def interleave(e, mfmas, fillers, first_gap=0):
         m()
         if i < first_gap:
             continue
-        want = (len(fillers) * (i - first_gap + 1) + gaps - 1) // gaps
+        if cap is None:
+            want = (len(fillers) * (i - first_gap + 1) + gaps - 1) // gaps
+        else:
+            want = min(len(fillers), done + cap)
+            left_gaps = n - 1 - i
+            want = max(want, len(fillers) - left_gaps * cap)      # never leave more than cap per remaining gap
         while done < want and done < len(fillers):
             fillers[done]()
             done += 1
@@ -209,47 +235,59 @@ def frag_read_fillers(e, stage, ks, dst_a, dst_b, order=None):
     return ops
 
 
-def glds_fillers(e, stage):
-    """the 16 direct-to-LDS loads of one k-step into `stage` (row group q = i * 4 + wave), each behind its M0 update"""
+def glds_fillers(e, stage, with_reads=()):
+    """the 16 direct-to-LDS loads of one k-step into `stage` (row group q = i * 4 + wave) as a chain of 17 thunks: thunk i issues
+    load i - 1 and then writes M0 for load i, so that something else (an MFMA, or the load itself) sits between a write of M0 and
+    the load that consumes it; `with_reads`: LDS reads to put at the head of the first thunks (one each)"""
+    reads = list(with_reads)
     ops = []
-    for i in range(16):
-        voff = RM.VOFFW + i if i < 8 else RM.VOFFX + (i - 8)
-        sbase = RM.S_LW if i < 8 else RM.S_LX
-        ops.append(lambda i=i, voff=voff, sbase=sbase: e.glds(voff, sbase, hex(stage * STAGE + i * 4096)))
-        ops.append(lambda: e.glds_issue())
+    for i in range(17):
+        def th(i=i):
+            if i < len(reads):
+                reads[i]()
+            if i >= 1:
+                e.glds_issue()
+            if i < 16:
+                voff = RM.VOFFW + i if i < 8 else RM.VOFFX + (i - 8)
+                e.glds(voff, RM.S_LW if i < 8 else RM.S_LX, hex(stage * STAGE + i * 4096))
+        ops.append(th)
+    assert len(reads) <= 17
     return ops
 
 
 def cursor_advance(e, uid):
     """load cursor: next k-step; at the end of a tile the next tile of this workgroup (or the same one again when none is left:
-    redundant loads that nobody consumes are simpler than a conditional pipeline).  BRANCH-FREE: the instructions are spread
-    between MFMAs, a taken branch would skip those."""
+    redundant loads that nobody consumes are simpler than a conditional pipeline).  The per-k-step part is six scalar instructions
+    that may be spread between MFMAs; the tile change is ONE contiguous run behind a branch (a taken branch must not skip MFMAs)."""
     T = RM.S_T
-    L = [
+    head = [
         f"s_add_u32 {s(RM.S_LW)}, {s(RM.S_LW)}, 128", f"s_addc_u32 {s(RM.S_LW + 1)}, {s(RM.S_LW + 1)}, 0",
         f"s_add_u32 {s(RM.S_LX)}, {s(RM.S_LX)}, 128", f"s_addc_u32 {s(RM.S_LX + 1)}, {s(RM.S_LX + 1)}, 0",
         f"s_sub_u32 {s(RM.S_LKT)}, {s(RM.S_LKT)}, 1",
+    ]
+    change = [
         f"s_cmp_eq_u32 {s(RM.S_LKT)}, 0",
-        f"s_cselect_b32 {s(T)}, 1, 0",                                  # T0 = this tile's loads are complete
+        f"s_cbranch_scc0 L_noadv_{uid}_%=",
         f"s_cmp_gt_u32 {s(RM.S_LLEFT)}, 1",
-        f"s_cselect_b32 {s(T + 1)}, {s(T)}, 0",                          # T1 = ... and another tile follows
+        f"s_cselect_b32 {s(T + 1)}, 1, 0",                              # T1 = another tile follows
         f"s_sub_u32 {s(RM.S_LLEFT)}, {s(RM.S_LLEFT)}, {s(T + 1)}",
         f"s_mul_i32 {s(T + 2)}, {s(RM.S_STM)}, {s(T + 1)}", f"s_add_u32 {s(RM.S_LMT)}, {s(RM.S_LMT)}, {s(T + 2)}",
         f"s_mul_i32 {s(T + 2)}, {s(RM.S_STN)}, {s(T + 1)}", f"s_add_u32 {s(RM.S_LNT)}, {s(RM.S_LNT)}, {s(T + 2)}",
         f"s_cmp_ge_u32 {s(RM.S_LNT)}, {s(RM.S_TN)}",
         f"s_cselect_b32 {s(T + 2)}, {s(RM.S_TN)}, 0", f"s_cselect_b32 {s(T + 3)}, 1, 0",
         f"s_sub_u32 {s(RM.S_LNT)}, {s(RM.S_LNT)}, {s(T + 2)}", f"s_add_u32 {s(RM.S_LMT)}, {s(RM.S_LMT)}, {s(T + 3)}",
-        # panel pointers of the (possibly new) tile at k = 0, taken only when T0
         f"s_lshl_b32 {s(T + 2)}, {s(RM.S_LNT)}, 8", f"s_mul_i32 {s(T + 2)}, {s(T + 2)}, {s(RM.S_WP)}",
-        f"s_add_u32 {s(T + 4)}, {s(RM.S_W)}, {s(T + 2)}", f"s_addc_u32 {s(T + 5)}, {s(RM.S_W + 1)}, 0",
+        f"s_add_u32 {s(RM.S_LW)}, {s(RM.S_W)}, {s(T + 2)}", f"s_addc_u32 {s(RM.S_LW + 1)}, {s(RM.S_W + 1)}, 0",
         f"s_lshl_b32 {s(T + 2)}, {s(RM.S_LMT)}, 8", f"s_mul_i32 {s(T + 2)}, {s(T + 2)}, {s(RM.S_XP)}",
-        f"s_add_u32 {s(T + 6)}, {s(RM.S_X)}, {s(T + 2)}", f"s_addc_u32 {s(T + 7)}, {s(RM.S_X + 1)}, 0",
-        f"s_cmp_eq_u32 {s(T)}, 1",
-        f"s_cselect_b32 {s(RM.S_LW)}, {s(T + 4)}, {s(RM.S_LW)}", f"s_cselect_b32 {s(RM.S_LW + 1)}, {s(T + 5)}, {s(RM.S_LW + 1)}",
-        f"s_cselect_b32 {s(RM.S_LX)}, {s(T + 6)}, {s(RM.S_LX)}", f"s_cselect_b32 {s(RM.S_LX + 1)}, {s(T + 7)}, {s(RM.S_LX + 1)}",
-        f"s_cselect_b32 {s(RM.S_LKT)}, {s(RM.S_NK)}, {s(RM.S_LKT)}",
+        f"s_add_u32 {s(RM.S_LX)}, {s(RM.S_X)}, {s(T + 2)}", f"s_addc_u32 {s(RM.S_LX + 1)}, {s(RM.S_X + 1)}, 0",
+        f"s_mov_b32 {s(RM.S_LKT)}, {s(RM.S_NK)}",
+        f"L_noadv_{uid}_%=:",
     ]
-    return [lambda t=t: e.ins(t) for t in L]
+
+    def run():
+        for t in change:
+            (e.raw if t.endswith(":") else e.ins)(t)
+    return [lambda t=t: e.ins(t) for t in head] + [run]
 
 
 def last_LA(nbp, nbl, ks):
@@ -284,12 +322,14 @@ def step_normal(e, p, first, uid, vm_entry=0, next_last=False):
             e.ins("s_barrier")
             # (the last-step layout lives in R[0:32) + R[64:80): clear of buffer 1 = R[32:64), which sub-step 3 is using)
             nxt = last_entry_reads(e, 1 - p) if next_last else frag_read_fillers(e, 1 - p, 0, na, nb_)
-            fillers = nxt + glds_fillers(e, p) + cursor_advance(e, uid)
+            fillers, cap = glds_fillers(e, p, with_reads=nxt), 1
         else:
             e.wait_lgkm0()
-            fillers = frag_read_fillers(e, p, ks + 1, na, nb_)
+            fillers, cap = frag_read_fillers(e, p, ks + 1, na, nb_), 1
+            if ks == 0:          # the load cursor moves on behind the batch the step before issued (entry contract of every step)
+                fillers, cap = fillers + cursor_advance(e, uid), 3
         mf = [lambda nb=nb, mb=mb: e.mfma(acc(nb, mb), fa[nb], fb[mb], zero=(first and ks == 0)) for nb in range(4) for mb in range(4)]
-        interleave(e, mf, fillers)
+        interleave(e, mf, fillers, cap=cap)
 
 
 def epilogue_E1(e, nbp, mb):
@@ -339,7 +379,7 @@ def step_last(e, p, uid):
         if sl == 0:
             fill += rd_a(1) + rd_b(1)
         if sl == 1:
-            fill += rd_b(2) + rd_b(3)
+            fill += rd_b(2) + rd_b(3) + cursor_advance(e, uid)      # (pending from the batch the step before issued)
         if sl >= 2:
             fill += epilogue_F1(e, (sl - 2) & 1, (sl - 2) >> 1)
         if sl >= 1:
@@ -348,9 +388,7 @@ def step_last(e, p, uid):
             e.ins(f"s_waitcnt vmcnt({e.vm_own}) lgkmcnt(0)")      # (nothing of mine is younger than the awaited batch yet)
             e.lgkm = []
             e.ins("s_barrier")
-            fill += glds_fillers(e, p)[:16]
-        if sl == 3:
-            fill += glds_fillers(e, p)[16:] + cursor_advance(e, uid)
+            fill = glds_fillers(e, p) + fill          # the whole batch FIRST: every store of this tile is younger than it
         if sl == 7:
             # sub-step-0 fragments of the next k-step (other stage) into buffer 0 = R[0:32): LA(0, ...) is free behind pair 6
             fill += frag_read_fillers(e, 1 - p, 0, [RM.R0 + nb * 4 for nb in range(4)], [RM.R0 + 16 + m * 4 for m in range(4)])
@@ -411,6 +449,7 @@ OP = {name: i for i, (_, name) in enumerate(OPERANDS)}
 
 
 def prologue(e):
+    e.in_prologue = True
     o = lambda name: f"%{OP[name]}"
     T, TV = RM.S_T, RM.TMP
     L = []
@@ -448,8 +487,9 @@ def prologue(e):
         e.ins(t)
     # k-steps 0 and 1 of the first tile in flight, the first one waited for, its sub-step-0 fragments requested
     for st in range(2):
-        for f in glds_fillers(e, st) + cursor_advance(e, f"pro{st}"):
+        for f in glds_fillers(e, st) + (cursor_advance(e, f"pro{st}") if st == 0 else []):
             f()
+        # (back to back in the prologue: the chain puts the write of M0 right in front of its load)
     e.ins("s_waitcnt vmcnt(16)")
     e.ins("s_barrier")
     for f in frag_read_fillers(e, 0, 0, [RM.R0 + nb * 4 for nb in range(4)], [RM.R0 + 16 + m * 4 for m in range(4)]):
@@ -504,15 +544,31 @@ def generate():
     return out, T_after
 
 
+PROBE_VARIANTS = {"NOMFMA": {"nomfma"}, "LOADS": {"nomfma", "noreads", "nostore"}, "NOGLDS": {"noglds"}, "NOSTORE": {"nostore"},
+                  "MFMAONLY": {"noglds", "nostore"},
+                  "NOGLDS_LAX": {"noglds", "laxvm"}, "MFMA_NOEPI": {"noglds", "nostore", "noepi"}}
+
+
 def emit_inc(path):
-    lines, _ = generate()
+    global OPTS
     with open(path, "w") as fh:
         fh.write("// GENERATED by zigma_amd/csrc/gen/linear4w_gen.py --emit — do not edit (tests/test_linear4w_gen.py checks it is current).\n")
         fh.write("// The main loop of linear4w_kernel as one asm statement; operands in the order of OPERANDS in the generator.\n")
-        fh.write("#define ZIGMA_LINEAR4W_BODY \\\n")
-        for ln in lines:
-            fh.write(f'    "{ln}\\n" \\\n')
-        fh.write("    \"\"\n")
+
+        def body(name, opts):
+            global OPTS
+            OPTS = set(opts)
+            lines, _ = generate()
+            OPTS = set()
+            fh.write(f"#define ZIGMA_LINEAR4W_BODY{name} \\\n")
+            for ln in lines:
+                fh.write(f'    "{ln}\\n" \\\n')
+            fh.write("    \"\"\n")
+        body("", ())
+        fh.write("#ifdef ZIGMA_LINEAR4W_PROBES   // timing probes (tools/linear4w_probe.py builds its own library with them): results are wrong\n")
+        for name, opts in PROBE_VARIANTS.items():
+            body("_" + name, opts)
+        fh.write("#endif\n")
         fh.write("#define ZIGMA_LINEAR4W_OPERANDS(" + ", ".join(n for _, n in OPERANDS) + ") \\\n    " +
                  ", ".join(f'"{c}"({n})' for c, n in OPERANDS) + "\n")
         cl = clobbers()

@@ -360,7 +360,7 @@ extern "C" int zigma_linear_fwd(const zigma_linear_params_t *pp, void *stream_) 
     (void)hipGetLastError();
     const zigma_linear_params_t &p = *pp;
     if (p.m < 0 || p.n < 1 || p.k < 1) return ZIGMA_ERR_SHAPE;
-    if (p.flags & ~0x3f00) return ZIGMA_ERR_UNSUPPORTED;     // 0x100 ... 0x1000: timing / A-B probes (tools/linear_probe.py); 0x2000: the 8-wave kernel
+    if (p.flags & ~0xf73f00) return ZIGMA_ERR_UNSUPPORTED;     // 0x100 ... 0x1000: timing / A-B probes (tools/linear_probe.py); 0x2000: the 8-wave kernel; 0x10000 .. 0x50000: probes of the 4-wave kernel (probe builds only)
     if (p.m == 0) return ZIGMA_OK;
     if (!p.x || !p.w || !p.out) return ZIGMA_ERR_NULL;
     if (p.dtype != ZIGMA_BF16) return ZIGMA_ERR_DTYPE;

@@ -19,6 +19,8 @@ namespace zigma {
 
 typedef __attribute__((address_space(3))) unsigned char *lds4w_ptr_t;
 
+// VARIANT: 0 = the kernel; 1 .. 5 = timing probes of tools/linear4w_probe.py (only in a library built with -DZIGMA_LINEAR4W_PROBES)
+template <int VARIANT>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
 void linear4w_kernel(const zigma_linear_params_t p, const int tiles_n, const int n_tiles) {
     __shared__ __attribute__((aligned(1024))) unsigned char smem[163840];
@@ -35,6 +37,10 @@ void linear4w_kernel(const zigma_linear_params_t p, const int tiles_n, const int
     const int step_m = wg_per_xcd / tiles_n, step_n = wg_per_xcd % tiles_n;
     const int mt0 = tile0 / tiles_n, nt0 = tile0 % tiles_n;
 
+#ifdef ZIGMA_LINEAR4W_PROBES
+    // start skew (probe): every CU finishes its tiles — and fires its 128 KB of stores — at the same moment otherwise
+    for (int i = 0, n = (static_cast<int>(blockIdx.x) * ((p.flags >> 20) & 15)) >> 3; i < n; ++i) __builtin_amdgcn_s_sleep(16);
+#endif
     const unsigned lds_base = static_cast<unsigned>(reinterpret_cast<uintptr_t>((lds4w_ptr_t)(smem)));
     const unsigned w_pitch = static_cast<unsigned>(p.w_row_stride * 2), x_pitch = static_cast<unsigned>(p.x_row_stride * 2),
                    o_pitch = static_cast<unsigned>(p.out_row_stride * 2);
@@ -52,15 +58,32 @@ void linear4w_kernel(const zigma_linear_params_t p, const int tiles_n, const int
     const unsigned stoff = t8 * o_pitch + u * 16;
     const void *w_ptr = p.w, *x_ptr = p.x;
     void *out_ptr = p.out;
-    asm volatile(ZIGMA_LINEAR4W_BODY
-                 :
-                 : ZIGMA_LINEAR4W_OPERANDS(voffw0, voffx0, a_base, b_base, t_xor, scrw_base, j7, scrr, stoff, w_ptr, x_ptr, out_ptr, w_pitch,
-                                           x_pitch, o_pitch, nk, tiles_n, my_tiles, step_m, step_n, mt0, nt0, wave, lds_base)
-                 : ZIGMA_LINEAR4W_CLOBBERS);
+#define ZIGMA_L4W_ASM(BODY_)                                                                                                                    \
+    asm volatile(BODY_                                                                                                                          \
+                 :                                                                                                                              \
+                 : ZIGMA_LINEAR4W_OPERANDS(voffw0, voffx0, a_base, b_base, t_xor, scrw_base, j7, scrr, stoff, w_ptr, x_ptr, out_ptr, w_pitch,  \
+                                           x_pitch, o_pitch, nk, tiles_n, my_tiles, step_m, step_n, mt0, nt0, wave, lds_base)                  \
+                 : ZIGMA_LINEAR4W_CLOBBERS)
+    if constexpr (VARIANT == 0) { ZIGMA_L4W_ASM(ZIGMA_LINEAR4W_BODY); }
+#ifdef ZIGMA_LINEAR4W_PROBES
+    else if constexpr (VARIANT == 1) { ZIGMA_L4W_ASM(ZIGMA_LINEAR4W_BODY_NOMFMA); }
+    else if constexpr (VARIANT == 2) { ZIGMA_L4W_ASM(ZIGMA_LINEAR4W_BODY_LOADS); }
+    else if constexpr (VARIANT == 3) { ZIGMA_L4W_ASM(ZIGMA_LINEAR4W_BODY_NOGLDS); }
+    else if constexpr (VARIANT == 4) { ZIGMA_L4W_ASM(ZIGMA_LINEAR4W_BODY_NOSTORE); }
+    else if constexpr (VARIANT == 5) { ZIGMA_L4W_ASM(ZIGMA_LINEAR4W_BODY_MFMAONLY); }
+    else if constexpr (VARIANT == 6) { ZIGMA_L4W_ASM(ZIGMA_LINEAR4W_BODY_NOGLDS_LAX); }
+    else if constexpr (VARIANT == 7) { ZIGMA_L4W_ASM(ZIGMA_LINEAR4W_BODY_MFMA_NOEPI); }
+#endif
+#undef ZIGMA_L4W_ASM
 }
 
 bool linear4w_eligible(const zigma_linear_params_t &p) {
-    if (p.bias || p.residual || p.flags || p.silu_from_col < p.n) return false;
+#ifdef ZIGMA_LINEAR4W_PROBES
+    if (p.flags & ~0xf70000) return false;                 // 0x10000 .. 0x50000: probe variant 1 .. 5; 0x100000 * k: start skew
+#else
+    if (p.flags) return false;
+#endif
+    if (p.bias || p.residual || p.silu_from_col < p.n) return false;
     if (p.m % 256 != 0 || p.n % 256 != 0 || p.k % 64 != 0 || p.k < 192) return false;
     if (p.out_row_stride % 8 != 0 || reinterpret_cast<uintptr_t>(p.out) % 16 != 0) return false;               // 16-byte stores
     if (p.m * p.out_row_stride * 2 > 0xffffffffll) return false;                                                // 32-bit tile offsets
@@ -71,7 +94,18 @@ bool linear4w_eligible(const zigma_linear_params_t &p) {
 int launch_linear4w(const zigma_linear_params_t &p, hipStream_t stream) {
     const int tiles_n = p.n / 256;
     const int n_tiles = static_cast<int>((p.m / 256) * tiles_n);
-    hipLaunchKernelGGL(linear4w_kernel, dim3(256), dim3(256), 0, stream, p, tiles_n, n_tiles);
+    switch ((p.flags >> 16) & 7) {
+#ifdef ZIGMA_LINEAR4W_PROBES
+        case 1: hipLaunchKernelGGL(linear4w_kernel<1>, dim3(256), dim3(256), 0, stream, p, tiles_n, n_tiles); break;
+        case 2: hipLaunchKernelGGL(linear4w_kernel<2>, dim3(256), dim3(256), 0, stream, p, tiles_n, n_tiles); break;
+        case 3: hipLaunchKernelGGL(linear4w_kernel<3>, dim3(256), dim3(256), 0, stream, p, tiles_n, n_tiles); break;
+        case 4: hipLaunchKernelGGL(linear4w_kernel<4>, dim3(256), dim3(256), 0, stream, p, tiles_n, n_tiles); break;
+        case 5: hipLaunchKernelGGL(linear4w_kernel<5>, dim3(256), dim3(256), 0, stream, p, tiles_n, n_tiles); break;
+        case 6: hipLaunchKernelGGL(linear4w_kernel<6>, dim3(256), dim3(256), 0, stream, p, tiles_n, n_tiles); break;
+        case 7: hipLaunchKernelGGL(linear4w_kernel<7>, dim3(256), dim3(256), 0, stream, p, tiles_n, n_tiles); break;
+#endif
+        default: hipLaunchKernelGGL(linear4w_kernel<0>, dim3(256), dim3(256), 0, stream, p, tiles_n, n_tiles);
+    }
     set_last_kernel("linear4w_256x256");
     return check_launch();
 }

@@ -22,13 +22,16 @@ def routes_to_4w(m, n, k, bias=None):
     return bias is None and m % 256 == 0 and n % 256 == 0 and k % 64 == 0 and k >= 192 and (m // 256) * (n // 256) >= 256
 
 
+AUTO_4W_MAX_N = int(os.environ.get("ZIGMA_4W_MAX_N", "1024"))   # "auto": the 4-wave kernel where it at least ties the library (to_q; not in_proj)
+
+
 def linear_eligible(x, weight, bias=None, fused_epilogue=False, prefer_own=False):
     """policy (LINEAR_POLICY) + limits of zigma_linear_fwd: bf16, k % 64 == 0, n % 128 == 0, tokens % 8 == 0, aligned contiguous
     rows, no autograd"""
     if not (LINEAR_POLICY != "off" and x.is_cuda and x.dtype == torch.bfloat16 and weight.dtype == torch.bfloat16):
         return False
     m_, (n_, k_) = x.numel() // max(x.shape[-1], 1), weight.shape
-    if LINEAR_POLICY == "auto" and bias is None and not fused_epilogue and not prefer_own and not routes_to_4w(m_, n_, k_):
+    if LINEAR_POLICY == "auto" and bias is None and not fused_epilogue and not prefer_own and not (routes_to_4w(m_, n_, k_) and n_ <= AUTO_4W_MAX_N):
         return False        # (auto: projections with an epilogue the library cannot fuse, and the wide ones the 4-wave kernel takes)
     if torch.is_grad_enabled() and (x.requires_grad or weight.requires_grad or (bias is not None and bias.requires_grad)):
         return False
