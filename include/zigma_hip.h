@@ -35,6 +35,8 @@ extern "C" {
 
 /* zigma_scan_params_t.flags */
 #define ZIGMA_SCAN_Z_PREACTIVATED 2   /* z already holds silu(z) (the in_proj GEMM epilogue applied it): out_z = y * z */
+#define ZIGMA_SCAN_PROBE_V1 0x100     /* A/B probe (tools/scan_ab.py): pin the first-generation token-major kernel */
+#define ZIGMA_SCAN_PROBE_PRIO_SHIFT 9 /* A/B probe: bit 9 = scan_tok2_kernel WITHOUT its wave-priority rotation */
 
 /* zigma_scan_params_t.info[0]: which kernel family served the call */
 #define ZIGMA_SCAN_KERNEL_GENERIC 1
@@ -82,7 +84,7 @@ typedef struct zigma_scan_params {
     int32_t io_dtype;   /* zigma_dtype_t of u, delta, z, out, out_z                                */
     int32_t bc_dtype;   /* zigma_dtype_t of VARIABLE B / C (reference: == io_dtype)               */
     int32_t chunk_len;  /* carry spacing for x; 0 -> 2048 (reference: selective_scan.cpp:307)      */
-    int32_t flags;      /* 0 or ZIGMA_SCAN_Z_PREACTIVATED (other bits reserved, must be 0)          */
+    int32_t flags;      /* 0 or ZIGMA_SCAN_Z_PREACTIVATED (+ ZIGMA_SCAN_PROBE_* bits; others must be 0)      */
 
     int64_t u_batch_stride, u_d_stride, u_l_stride;
     int64_t delta_batch_stride, delta_d_stride, delta_l_stride;

@@ -155,10 +155,8 @@ def test_scan_tok2_hot_kernel_matches_first_generation_and_preactivated_gate(dty
     info = []
     y2, _ = _run_tok(c, dtype, info=info)
     assert info == [_lib.SCAN_KERNEL_TOK2, 0] and _lib.last_kernel() == "scan_tok2_n16"
-    monkeypatch.setenv("ZIGMA_SCAN_KERNEL", "v1")
     info1 = []
-    y1, _ = _run_tok(c, dtype, info=info1)
-    monkeypatch.delenv("ZIGMA_SCAN_KERNEL")
+    y1, _ = _run_tok(c, dtype, info=info1, _probe_flags=_lib.SCAN_PROBE_V1)
     # same products in the same order; only the sum of the four waves' partials associates differently (fp32), which
     # moves a few 16-bit results by one ulp
     assert info1[0] == _lib.SCAN_KERNEL_TOK and rel_err(N(y2), N(y1)) < 5e-4

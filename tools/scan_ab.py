@@ -1,5 +1,5 @@
 """A/B of the token-major scan kernels at the headline shape as the model calls it (B=64, L=1024, Di=1280, N=16, bf16, delta
-already softplus'ed by the dt_proj kernel, gate only, zigzag row tables): first-generation scan_tok_kernel (ZIGMA_SCAN_KERNEL=v1)
+already softplus'ed by the dt_proj kernel, gate only, zigzag row tables): first-generation scan_tok_kernel (probe flag ZIGMA_SCAN_PROBE_V1)
 against scan_tok2_kernel, interleaved rounds in ONE process (cdna_hip_programming.md §5.4 rule 24), plus the
 z-preactivated variant (SiLU moved out of the kernel).  Prints one JSON line."""
 import json, os, sys, torch
@@ -22,7 +22,6 @@ db = torch.rand(Di, device=dev)
 
 def run_sp(name):
     """softplus(delta + bias) evaluated INSIDE the kernel's prologue (what a caller without the dt_proj kernel gets)"""
-    os.environ.pop("ZIGMA_SCAN_KERNEL", None)
     y = outs.setdefault(name, torch.empty(B, L, Di, device=dev, dtype=dt))
     scan_raw(u.transpose(1, 2), delta.transpose(1, 2), A, Bv, Cv, D, xz[:, :, Di:].transpose(1, 2), db, True,
              out_z=y.transpose(1, 2), z_row_index=perm, out_row_index=perm, want_out=False)
@@ -30,17 +29,15 @@ def run_sp(name):
 
 
 def run(name, env, zact=False):
-    if env:
-        os.environ["ZIGMA_SCAN_KERNEL"] = env
-    else:
-        os.environ.pop("ZIGMA_SCAN_KERNEL", None)
+    fl = _lib.SCAN_PROBE_V1 if env == "v1" else (int(env[4:]) << _lib.SCAN_PROBE_PRIO_SHIFT) if env and env.startswith("prio") else 0
     y = outs.setdefault(name, torch.empty(B, L, Di, device=dev, dtype=dt))
     scan_raw(u.transpose(1, 2), delta.transpose(1, 2), A, Bv, Cv, D, xz[:, :, Di:].transpose(1, 2), None, False,
-             out_z=y.transpose(1, 2), z_row_index=perm, out_row_index=perm, want_out=False, z_preactivated=zact)
+             out_z=y.transpose(1, 2), z_row_index=perm, out_row_index=perm, want_out=False, z_preactivated=zact, _probe_flags=fl)
     return _lib.last_kernel()
 
 
-variants = [("v1", "v1", False), ("v2", None, False), ("v2_zact", None, True), ("v2_softplus_inside", "SP", False)]
+variants = [("v1", "v1", False), ("v2", None, False), ("v2_zact", None, True), ("v2_softplus_inside", "SP", False)] + \
+           [("v2_no_prio_rotation", "prio1", False)]
 _run = run
 run = lambda n, e, z=False: run_sp(n) if e == "SP" else _run(n, e, z)
 names = {n: run(n, e, z) for n, e, z in variants}
@@ -59,5 +56,6 @@ res = dict(shape=f"B={B} L={L} Di={Di} N={N} bf16", kernels=names,
            us_median={n: sorted(v)[len(v) // 2] for n, v in times.items()}, us_min={n: min(v) for n, v in times.items()},
            hbm_frac_of_8TBps={n: by / (sorted(v)[len(v) // 2] * 1e-6) / 8e12 for n, v in times.items()},
            max_abs_diff_v2_vs_v1=float((outs["v2"].float() - outs["v1"].float()).abs().max()),
-           bit_identical=bool(torch.equal(outs["v2"], outs["v1"])))
+           bit_identical=bool(torch.equal(outs["v2"], outs["v1"])),
+           prio_variants_identical=bool(torch.equal(outs["v2"], outs["v2_no_prio_rotation"])))
 print(json.dumps(res))

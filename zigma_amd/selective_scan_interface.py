@@ -65,7 +65,7 @@ def _as_bgnl(M, name):
 
 def scan_raw(u, delta, A, B, C, D=None, z=None, delta_bias=None, delta_softplus=False, *, out=None, out_z=None,
              x=None, z_row_index=None, out_row_index=None, want_out=True, checkpoints=None, reset_period=0,
-             chunk_len=2048, z_preactivated=False, info=None):
+             chunk_len=2048, z_preactivated=False, info=None, _probe_flags=0):
     """Launch zigma_selective_scan_fwd.  All tensors are logical (batch, dim, seqlen) VIEWS with arbitrary
     strides (token-major tensors come in as `.transpose(1, 2)`); B/C are (D, N) f32 or (B, G, N, L) views.
     Outputs that are None are allocated here with the reference's conventions (out like delta, out_z like z).
@@ -91,7 +91,7 @@ def scan_raw(u, delta, A, B, C, D=None, z=None, delta_bias=None, delta_softplus=
     P.batch, P.dim, P.seqlen, P.dstate = batch, dim, L, N
     P.delta_softplus = int(bool(delta_softplus))
     P.io_dtype = _lib.dtype_id(u)
-    P.chunk_len, P.flags = int(chunk_len), (_lib.SCAN_Z_PREACTIVATED if z_preactivated else 0)
+    P.chunk_len, P.flags = int(chunk_len), (_lib.SCAN_Z_PREACTIVATED if z_preactivated else 0) | int(_probe_flags)
     P.is_variable_B, P.is_variable_C = int(var_b), int(var_c)
     groups = 1
     bc_dt = None
