@@ -220,6 +220,76 @@ def test_scan_tok2_vs_oracle_sweep(dtype, L, Di, use_perm, split):
         assert rel_err(N(x[:, :, -1, 1::2]), last) < 2e-5
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("Tq,nseq", [(16, 4), (32, 3), (64, 2)])
+def test_scan_tok2_reset_period_vs_oracle(dtype, Tq, nseq):
+    """reset_period on the hot kernel (the video temporal layers, mamba_simple.py:420-440 without the transposing copies): a batch
+    row is `nseq` independent sequences of Tq steps back to back — against the numpy oracle run on every sequence SEPARATELY (the
+    state must restart, nothing may leak across a boundary), with row tables that stay inside each sequence."""
+    from zigma_amd import _lib
+    from zigma_amd.selective_scan_interface import scan_raw
+    Bsz, Di, Nst, R = 3, 128, 16, 8
+    L = Tq * nseq
+    c = _tok_case(Bsz, L, Di, Nst, torch.float32, True, False, seed=Tq + nseq)
+    for k in ("u", "delta", "xdbl", "zfull"):
+        c[k] = _round_to(c[k], dtype)
+    rng = np.random.default_rng(Tq)
+    perm = np.concatenate([q * Tq + rng.permutation(Tq) for q in range(nseq)]).astype(np.int64)
+    u, delta, xdbl, zfull = (T(c[k], dtype) for k in ("u", "delta", "xdbl", "zfull"))
+    pt = torch.from_numpy(perm.astype(np.int32)).to(DEV)
+    y = torch.empty(Bsz, L, Di, device=DEV, dtype=dtype)
+    info = []
+    scan_raw(u.transpose(1, 2), delta.transpose(1, 2), T(c["A"]), xdbl[:, :, R:R + Nst].transpose(1, 2).unsqueeze(1),
+             xdbl[:, :, R + Nst:].transpose(1, 2).unsqueeze(1), T(c["D"]), zfull[:, :, Di:].transpose(1, 2), T(c["db"]), True,
+             out_z=y.transpose(1, 2), z_row_index=pt, out_row_index=pt, want_out=False, reset_period=Tq, info=info)
+    assert info[0] == _lib.SCAN_KERNEL_TOK2 and _lib.last_kernel() == "scan_tok2_n16"
+    ref = np.zeros((Bsz, L, Di), np.float32)
+    tr = lambda a: a.transpose(0, 2, 1)
+    for q in range(nseq):
+        sl = slice(q * Tq, (q + 1) * Tq)
+        z = c["zfull"][:, :, Di:][:, perm[sl]]
+        o = zo.selective_scan(tr(c["u"][:, sl]), tr(c["delta"][:, sl]), c["A"], tr(c["xdbl"][:, sl, R:R + Nst]), tr(c["xdbl"][:, sl, R + Nst:]),
+                              c["D"], tr(z), c["db"], True)
+        ref[:, perm[sl]] = tr(o)
+    ref = _round_to(ref, dtype)
+    assert rel_err(N(y), ref) < (1e-3 if dtype == torch.bfloat16 else 3e-4)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("L,Di,use_perm", [(64, 192, True), (1024, 128, False), (48, 64, True)])
+def test_scan_tok2_training_form_vs_oracle(dtype, L, Di, use_perm):
+    """The training forward on the hot kernel (MambaInnerFn.forward saves the ungated scan output, selective_scan_interface.py:346-
+    365): out_z AND the ungated `out` against the oracle, and the checkpoints (state before every 16-step tile, consumed by
+    zigma_selective_scan_bwd) against a float64 recurrence and against the first-generation kernel's."""
+    from zigma_amd import _lib
+    c = _tok_case(2, L, Di, 16, torch.float32, True, use_perm, seed=L + Di)
+    for k in ("u", "delta", "xdbl", "zfull"):
+        c[k] = _round_to(c[k], dtype)
+    outs = {}
+    for tag, fl in (("tok2", 0), ("v1", _lib.SCAN_PROBE_V1)):
+        ck = torch.full((2, Di // 64, L // 16, 16, 64), float("nan"), device=DEV)
+        out = torch.empty(2, L, Di, device=DEV, dtype=dtype)
+        info = []
+        y, _ = _run_tok(c, dtype, info=info, out=out.transpose(1, 2), checkpoints=ck, _probe_flags=fl)
+        assert info == [_lib.SCAN_KERNEL_TOK2 if tag == "tok2" else _lib.SCAN_KERNEL_TOK, 1], (tag, info)
+        outs[tag] = (y, out, ck)
+    y, out, ck = outs["tok2"]
+    ref_z, _ = _oracle_tok(c, torch.float32)
+    ref_o, _ = _oracle_tok(dict(c, has_z=False), torch.float32)
+    tol = 1e-3 if dtype == torch.bfloat16 else 3e-4
+    assert rel_err(N(y), _round_to(ref_z, dtype)) < tol and rel_err(N(out), _round_to(ref_o, dtype)) < tol
+    assert rel_err(N(ck), N(outs["v1"][2])) < 1e-5 and not torch.isnan(ck).any()
+    # float64 recurrence for the states before every tile, sample 1, slab 0
+    R = c["R"]
+    dl = np.log1p(np.exp(np.minimum(c["delta"][1, :, :64].astype(np.float64) + c["db"][:64], 20)))
+    dl = np.where(c["delta"][1, :, :64] + c["db"][:64] > 20, c["delta"][1, :, :64] + c["db"][:64], dl)
+    h = np.zeros((64, 16))
+    for k in range(L):
+        if k % 16 == 0:
+            assert rel_err(N(ck[1, 0, k // 16]).T, h) < 2e-5 or np.abs(h).max() == 0
+        h = np.exp(dl[k][:, None] * c["A"][:64].astype(np.float64)) * h + (dl[k] * c["u"][1, k, :64])[:, None] * c["xdbl"][1, k, R:R + 16][None, :]
+
+
 @pytest.mark.parametrize("slabs_b,Di", [(2, 64), (33, 64 * 64), (65, 64 * 64)])
 def test_scan_tok_state_split_variants(slabs_b, Di):
     """the dispatcher picks 4 / 8 / 16 states per wave by problem size; all must agree with the oracle"""
