@@ -832,7 +832,10 @@ def test_linear4w_kernel(M, K, N, monkeypatch):
     g = torch.Generator(device="cpu").manual_seed(M + N + K)
     x = torch.randn(M, K, generator=g).to(DEV, torch.bfloat16)
     w = (torch.randn(N, K, generator=g) * K ** -0.5).to(DEV, torch.bfloat16)
-    assert routes_to_4w(M, N, K) and linear_eligible(x, w, None)          # default policy
+    assert routes_to_4w(M, N, K)
+    assert linear_eligible(x, w, None) == (N <= zl.AUTO_4W_MAX_N)       # default policy: where the kernel at least ties the library
+    monkeypatch.setattr(zl, "LINEAR_POLICY", "all")
+    assert linear_eligible(x, w, None)
     y = linear(x, w)
     assert _lib.last_kernel() == "linear4w_256x256" and y.shape == (M, N)
     rows = torch.randint(0, M, (1024,), generator=g).to(DEV)
