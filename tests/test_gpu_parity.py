@@ -856,6 +856,42 @@ def test_linear4w_kernel(M, K, N, monkeypatch):
         assert torch.equal(wide[:, 128:128 + N], y) and float(wide[:, :128].abs().max()) == 0 and float(wide[:, 128 + N:].abs().max()) == 0
 
 
+@pytest.mark.parametrize("Bsz,L,K,N,bias,res", [(64, 1024, 1280, 640, False, False), (64, 1024, 1280, 640, False, True), (64, 1024, 512, 640, True, True),
+                                                 (32, 2048, 192, 384, False, True), (128, 256, 256, 1152, True, True)])
+def test_linear4w_narrow_tiles_and_gated_residual(Bsz, L, K, N, bias, res, monkeypatch):
+    """The 4-wave kernel on n % 256 == 128 (a 128-wide tile behind the 256-wide ones) and with the block's gated branch add in its
+    epilogue (+ bias as a rank-1 MFMA): out = residual + gate[b] * (x W^T + bias) against float64 on the same bf16 operands for
+    sampled rows of every sample position class, against the 8-wave kernel (which rounds x W^T + b to bf16 before the gate: the two
+    differ by that rounding only), run-to-run identity."""
+    from zigma_amd import _lib
+    import zigma_amd.linear as zl
+    from zigma_amd.linear import linear
+    monkeypatch.setattr(zl, "LINEAR_POLICY", "all")
+    g = torch.Generator(device="cpu").manual_seed(Bsz + K + N)
+    M = Bsz * L
+    x = torch.randn(Bsz, L, K, generator=g).to(DEV, torch.bfloat16)
+    w = (torch.randn(N, K, generator=g) * K ** -0.5).to(DEV, torch.bfloat16)
+    b = (torch.randn(N, generator=g) * 0.5).to(DEV, torch.bfloat16) if bias else None
+    r = torch.randn(Bsz, L, N, generator=g).to(DEV, torch.bfloat16) if res else None
+    gt = torch.randn(Bsz, N, generator=g).to(DEV, torch.bfloat16) if res else None
+    y = linear(x, w, b, residual=r, gate=gt)
+    assert _lib.last_kernel() == ("linear4w_256x256+128" if N % 256 else "linear4w_256x256"), _lib.last_kernel()
+    rows = torch.randint(0, M, (768,), generator=g).to(DEV)
+    rows[:6] = torch.tensor([0, 127, 128, L - 1, L % M, M - 1], device=DEV)
+    val = x.view(M, K)[rows].double() @ w.double().T + (b.double() if bias else 0)
+    ref = val if not res else r.view(M, N)[rows].double() + gt[rows // L].double() * val
+    got = y.view(M, N)[rows].double()
+    assert float((got - ref).norm() / ref.norm()) < 2.5e-3
+    assert torch.allclose(got, ref, rtol=1.6e-2, atol=2e-2)
+    y8 = linear(x, w, b, residual=r, gate=gt, _probe_flags=0x2000)
+    assert _lib.last_kernel().startswith("linear_tn_")
+    assert float((y.float() - y8.float()).norm() / y8.float().norm()) < 4e-3
+    if not res:
+        assert torch.equal(y, y8)
+    for _ in range(3):
+        assert torch.equal(linear(x, w, b, residual=r, gate=gt), y)
+
+
 @pytest.mark.parametrize("Bsz,L,K,Nn,bias", [(2, 256, 512, 640, True), (3, 512, 128, 128, False), (16, 1024, 512, 640, True)])
 def test_linear_gated_residual_epilogue(Bsz, L, K, Nn, bias, monkeypatch):
     """out = residual + gate[b] * bf16(x @ W^T + bias) in the projection kernel's epilogue (the block's gated branch add) vs the

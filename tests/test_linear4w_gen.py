@@ -21,17 +21,31 @@ def test_committed_inc_is_current(tmp_path):
         "run `python zigma_amd/csrc/gen/linear4w_gen.py --emit`"
 
 
-@pytest.mark.parametrize("M,N,K,n_wg,wg,order", [
-    (256, 256, 192, 8, 0, (0, 1, 2, 3)),          # one tile, three k-steps: FIRST -> NORMAL-before-last -> LAST
-    (1024, 768, 192, 8, 0, (3, 2, 1, 0)),         # two tiles, odd k-step count: the stage parity alternates between tiles
-    (1024, 768, 320, 8, 1, (0, 1, 2, 3)),         # tile list that wraps to the next m-tile; plain NORMAL steps
-    (512, 256, 256, 8, 1, (1, 3, 0, 2)),          # even k-step count
-    (4096, 512, 192, 16, 9, (0, 1, 2, 3)),        # two workgroups per XCD: tile stride 2
-])
-def test_generated_loop_in_the_simulator(M, N, K, n_wg, wg, order):
+def _cases():
     import linear4w_sim as S
-    r = S.check(M, N, K, n_wg, wg, order)
+    return S.CASES
+
+
+@pytest.mark.parametrize("case", range(12))
+def test_generated_loop_in_the_simulator(case):
+    """every kernel variant (256-wide tiles only / + 128-wide remainder / + gated residual / + bias), tile lists that change width,
+    wrap to the next m-tile, odd and even k-step counts, all four wave orders between barriers"""
+    import linear4w_sim as S
+    M, N, K, n_wg, wg, order, cfg, rpb = S.CASES[case]
+    r = S.check(M, N, K, n_wg, wg, order, cfg=cfg, rows_per_batch=rpb)
     assert r is not None and r[0] < 3e-3
+
+
+def test_register_ranges_are_aligned():
+    """the assembler wants 64-bit scalar pairs on even and 128-bit scalar quads on multiples of four (the simulator does not care)"""
+    import re
+    import linear4w_gen as G
+    for cfg in G.VARIANTS.values():
+        lines, _ = G.generate(cfg)
+        for ln in lines:
+            for a, b in re.findall(r"s\[(\d+):(\d+)\]", ln):
+                n = int(b) - int(a) + 1
+                assert int(a) % (4 if n == 4 else 2) == 0, ln
 
 
 def test_simulator_catches_a_missing_wait():
@@ -39,7 +53,7 @@ def test_simulator_catches_a_missing_wait():
     import linear4w_gen as G
     import linear4w_sim as S
     lines, T = G.generate()
-    start = lines.index("L_first0_%=:")                                    # (a block this problem executes)
+    start = lines.index("L_first0_w_0_%=:")                                    # (a block this problem executes)
     i = next(k for k in range(start, len(lines)) if lines[k].startswith("s_waitcnt vmcnt(0) lgkmcnt(0)") and "s_barrier" in lines[k + 1])
     broken = lines[:i] + ["s_waitcnt lgkmcnt(0)"] + lines[i + 1:]          # the boundary no longer waits for the direct-to-LDS loads
     with pytest.raises(S.SimError):

@@ -43,18 +43,26 @@ LDS_BYTES = SCRATCH + 4 * 8192    # 163 840 = the CU's whole LDS
 
 class RegMap:
     """literal registers of the asm body"""
-    R0 = 32                       # fragment pool R[0:128) = v32..v159
-    ROW = 160                     # 8 x 4: rows read back from the scratch (fp32)
-    PK = 192                      # 4 x 4: packed bf16 rows, store data
-    VOFFW = 208                   # 8: per-lane source offsets of the W-row direct-to-LDS loads
+    R0 = 32                       # fragment pool R[0:128) = v32..v159 (normal steps use R[0:64); R[64:128) holds per-tile temporaries then)
+    ROW = 160                     # 2 x 8: one group of 8 output rows read back from the scratch (fp32), double-buffered
+    RES = 176                     # 2 x 4: the residual rows of that group (gated-residual epilogue)
+    PK = 184                      # 2 x 4: packed bf16 rows, store data
+    G = 192                       # 16: gate of this wave tile's sample as fp32, [feature pair][8 features of the lane]
+    VOFFW = 208                   # 8: per-lane source offsets of the W-row direct-to-LDS loads (wide tile)
     VOFFX = 216                   # 8: ... of the token rows
     AADDR = 224                   # [stage][ks]: fragment read addresses of the W rows
     BADDR = 232                   # [stage][ks]: ... token rows
     SCRW = 240                    # 8: scratch write addresses [(blk, q)]
     SCRR = 248                    # scratch read address
-    STOFF = 249                   # store offset of this lane inside a group of 8 output rows
-    TMP = 250                     # 250..255 scratch for the prologue
-    # SGPRs
+    STOFF = 249                   # store offset of this lane inside a group of 8 output rows (residual rows: the same)
+    VOFFWE = 250                  # 4: W-row offsets of loads 4..7 for the tile the load cursor is on (narrow tiles re-map them)
+    TMP = 254                     # 254, 255 scratch
+    # temporaries of a tile's first steps, inside R[96:128) (the step before the last one prefetches into R[0:32) and R[64:80))
+    BIASA = R0 + 96               # 4 x 4: A fragments [bias, 0, 0, 0] of the rank-1 bias product
+    ONES = R0 + 112               # 4: B fragment [1.0 in k = 0, 0 ...]
+    GRAW = R0 + 116               # 2 x 4: the gate rows as loaded (bf16)
+    GOFF = R0 + 124               # (lane & 7) * 16
+    # SGPRs (mutable state; read-only inputs are used as operands where they arrive)
     S_W, S_X, S_OUT = 36, 38, 40                       # 64-bit bases
     S_WP, S_XP, S_OP = 42, 43, 44                      # row pitches in bytes
     S_NK, S_TN, S_TLEFT, S_STM, S_STN = 45, 46, 47, 48, 49
@@ -62,10 +70,15 @@ class RegMap:
     S_LW, S_LX = 54, 56                                # 64-bit: current W / X panel pointers of the load cursor (incl. k offset)
     S_CMT, S_CNT, S_KCNT = 58, 59, 60                  # compute cursor, normal k-steps left in this tile
     S_WM, S_WN = 61, 62                                # wave's token half / feature half
+    S_CNARROW = 63                                     # the compute tile is a narrow one (128 features)
     S_RS = 64                                          # 64..67 output buffer descriptor of the wave tile
     S_SO = 68                                          # 68..83: store row-group offsets [(mb, g)] = (mb*32 + g*8) * out pitch
     S_LDSW = 84                                        # wave * 1024 (+ LDS base): direct-to-LDS destination of this wave inside a row group
-    S_T = 86                                           # 86..95 temporaries
+    S_NWIDE = 85                                       # number of 256-wide n-tiles (a narrow tile, if any, has index S_NWIDE)
+    S_T = 86                                           # 86..91 temporaries
+    S_RRS = 92                                         # 92..95 residual buffer descriptor of the wave tile
+    S_BRS = 96                                         # 96..99 bias descriptor of the wave tile
+    S_GP = 100                                         # 100..101 gate row pointer of the wave tile
 
 
 RM = RegMap
@@ -94,13 +107,15 @@ def acc(nb, mb):
 # ------------------------------------------------------------------------------------------------------------------
 # emitter with issue log: counted waits are derived from it
 # ------------------------------------------------------------------------------------------------------------------
-OPTS = set()       # probe variants (timing only, results wrong): "nomfma", "noreads", "noglds", "nostore"
+OPTS = set()       # probe variants (timing only, results wrong): "nomfma", "noreads", "noglds", "nostore", "laxvm", "noepi"
+CFG = dict(narrow=False, res=False, bias=False)     # what the body being generated supports (see VARIANTS)
 
 
 class Emit:
     def __init__(self):
         self.lines = []
         self.lgkm = []          # outstanding LDS ops of this block, oldest first: sets of destination registers (or None)
+        self.vmq = []           # outstanding vector-memory ops of this block, oldest first: destination register sets (or None)
         self.vm_after_glds = None   # number of vector-memory ops issued after the last direct-to-LDS load (None: no such load yet in this block)
         self.vm_own = 0         # vector-memory ops issued in this block so far
         self.n_inst = 0
@@ -119,9 +134,6 @@ class Emit:
         self.n_inst += 1
         if text.startswith("s_nop"):
             self.n_inst += int(text.split()[1])          # wait states
-
-    def label(self, name):
-        self.lines.append(f"{name}:")
 
     # --- LDS ---------------------------------------------------------------------------------------------
     def ds_read(self, dst, addr_v, off):
@@ -159,11 +171,31 @@ class Emit:
         self.ins(f"s_waitcnt lgkmcnt({k})")
         self.lgkm = self.lgkm[last + 1:]
 
+    def need_vm(self, regs):
+        """the same for vector loads of this block (the counter retires in issue order, loads and stores alike)"""
+        regs = set(regs)
+        last = -1
+        for i, d in enumerate(self.vmq):
+            if d is not None and d & regs:
+                last = i
+        if last < 0:
+            return
+        k = len(self.vmq) - 1 - last
+        assert k <= 63
+        self.ins(f"s_waitcnt vmcnt({k})")
+        self.vmq = self.vmq[last + 1:]
+
     def wait_lgkm0(self):
         self.ins("s_waitcnt lgkmcnt(0)")
         self.lgkm = []
 
     # --- vector memory ------------------------------------------------------------------------------------
+    def _vm(self, dst=None):
+        self.vm_own += 1
+        self.vmq.append(dst)
+        if self.vm_after_glds is not None:
+            self.vm_after_glds += 1
+
     def glds(self, voff_v, sbase, m0_expr):
         self.ins(f"s_add_u32 m0, {s(RM.S_LDSW)}, {m0_expr}")
         self.pending_glds = (voff_v, sbase)
@@ -176,16 +208,18 @@ class Emit:
         if self.lines[-1].startswith("s_add_u32 m0"):          # one wait state between the write of M0 and its consumer
             self.ins("s_nop 0")
         self.ins(f"global_load_lds_dwordx4 {v(voff_v)}, {s(sbase, 2)}")
-        self.vm_own += 1
+        self._vm()
         self.vm_after_glds = 0
 
     def store(self, data, soff, imm):
         if "nostore" in OPTS:
             return
         self.ins(f"buffer_store_dwordx4 {v(data, 4)}, {v(RM.STOFF)}, {s(RM.S_RS, 4)}, {s(soff)} offen offset:{imm}")
-        self.vm_own += 1
-        if self.vm_after_glds is not None:
-            self.vm_after_glds += 1
+        self._vm()
+
+    def res_load(self, dst, soff, imm):
+        self.ins(f"buffer_load_dwordx4 {v(dst, 4)}, {v(RM.STOFF)}, {s(RM.S_RRS, 4)}, {s(soff)} offen offset:{imm}")
+        self._vm(set(range(dst, dst + 4)))
 
     def mfma(self, c, fa, fb, zero=False):
         if "nomfma" in OPTS:
@@ -220,13 +254,17 @@ def interleave(e, mfmas, fillers, first_gap=0, cap=None):
         done += 1
 
 
+def o(name):
+    return f"%{OP[name]}"
+
+
 # ------------------------------------------------------------------------------------------------------------------
 # pieces
 # ------------------------------------------------------------------------------------------------------------------
-def frag_read_fillers(e, stage, ks, dst_a, dst_b, order=None):
-    """the 8 fragment reads of sub-step ks from `stage`: A (W rows) blocks nb -> dst_a[nb], B (token rows) blocks mb -> dst_b[mb]"""
+def frag_read_fillers(e, stage, ks, dst_a, dst_b, nbw=4):
+    """the fragment reads of sub-step ks from `stage`: A (W rows) blocks nb < nbw -> dst_a[nb], B (token rows) blocks mb -> dst_b[mb]"""
+    seq = [("a", 0), ("b", 0), ("b", 1), ("b", 2), ("b", 3)] + [("a", i) for i in range(1, nbw)]
     ops = []
-    seq = order or [("a", 0), ("b", 0), ("b", 1), ("b", 2), ("b", 3), ("a", 1), ("a", 2), ("a", 3)]
     for kind, i in seq:
         if kind == "a":
             ops.append(lambda i=i: e.ds_read(dst_a[i], RM.AADDR + stage * 4 + ks, i * 4096))
@@ -238,7 +276,9 @@ def frag_read_fillers(e, stage, ks, dst_a, dst_b, order=None):
 def glds_fillers(e, stage, with_reads=()):
     """the 16 direct-to-LDS loads of one k-step into `stage` (row group q = i * 4 + wave) as a chain of 17 thunks: thunk i issues
     load i - 1 and then writes M0 for load i, so that something else (an MFMA, or the load itself) sits between a write of M0 and
-    the load that consumes it; `with_reads`: LDS reads to put at the head of the first thunks (one each)"""
+    the load that consumes it; `with_reads`: LDS reads to put at the head of the first thunks (one each).
+    W-row loads 4..7 take their offsets from VOFFWE: on a narrow tile (128 features; wave half wn reads LDS rows wn * 128 + [0, 64))
+    they fetch features 64..127 (and, harmlessly, once more) instead of rows that a last n-tile does not have."""
     reads = list(with_reads)
     ops = []
     for i in range(17):
@@ -248,11 +288,24 @@ def glds_fillers(e, stage, with_reads=()):
             if i >= 1:
                 e.glds_issue()
             if i < 16:
-                voff = RM.VOFFW + i if i < 8 else RM.VOFFX + (i - 8)
+                voff = (RM.VOFFW + i if i < 4 else RM.VOFFWE + (i - 4)) if i < 8 else RM.VOFFX + (i - 8)
                 e.glds(voff, RM.S_LW if i < 8 else RM.S_LX, hex(stage * STAGE + i * 4096))
         ops.append(th)
     assert len(reads) <= 17
     return ops
+
+
+def voffwe_update():
+    """VOFFWE for the tile the load cursor is on (contiguous code, not to be spread between MFMAs)"""
+    L = []
+    if CFG["narrow"]:
+        L += [f"s_cmp_eq_u32 {s(RM.S_LNT)}, {s(RM.S_NWIDE)}", f"s_cbranch_scc1 L_vwn_@_%="]
+    L += [f"v_mov_b32 {v(RM.VOFFWE + k)}, {v(RM.VOFFW + 4 + k)}" for k in range(4)]
+    if CFG["narrow"]:
+        L += ["s_branch L_vwd_@_%=", "L_vwn_@_%=:"]
+        L += [f"v_mov_b32 {v(RM.VOFFWE + k)}, {v(RM.VOFFW + 2 + (k & 1))}" for k in range(4)]
+        L += ["L_vwd_@_%=:"]
+    return L
 
 
 def cursor_advance(e, uid):
@@ -281,8 +334,7 @@ def cursor_advance(e, uid):
         f"s_lshl_b32 {s(T + 2)}, {s(RM.S_LMT)}, 8", f"s_mul_i32 {s(T + 2)}, {s(T + 2)}, {s(RM.S_XP)}",
         f"s_add_u32 {s(RM.S_LX)}, {s(RM.S_X)}, {s(T + 2)}", f"s_addc_u32 {s(RM.S_LX + 1)}, {s(RM.S_X + 1)}, 0",
         f"s_mov_b32 {s(RM.S_LKT)}, {s(RM.S_NK)}",
-        f"L_noadv_{uid}_%=:",
-    ]
+    ] + [t.replace("@", uid) for t in voffwe_update()] + [f"L_noadv_{uid}_%=:"]
 
     def run():
         for t in change:
@@ -305,31 +357,72 @@ def last_entry_reads(e, stage):
     return ops
 
 
-def step_normal(e, p, first, uid, vm_entry=0, next_last=False):
+# ---- per-tile epilogue operands: gate (gated-residual epilogue) and bias, fetched in a tile's FIRST step ----------
+def tile_operand_loads_emit(e, nbw):
+    """FIRST step, sub-step 0 (contiguous): raw gate rows -> GRAW, bias values -> BIASA[nb][0] (lanes >= 32 read out of range: 0),
+    zeros / ones of the rank-1 fragments.  The loads are older than this step's direct-to-LDS batch, so the NEXT step's boundary
+    wait covers them (nk >= 3: there is one before the values are used)."""
+    if CFG["res"]:
+        e.ins(f"v_and_b32 {v(RM.GOFF)}, 0x70, {v(RM.STOFF)}")                       # (lane & 7) * 16: the out pitch is a multiple of 256
+        for nbp in range(nbw // 2):
+            e.ins(f"global_load_dwordx4 {v(RM.GRAW + 4 * nbp, 4)}, {v(RM.GOFF)}, {s(RM.S_GP, 2)} offset:{nbp * 128}")
+            e._vm(None)
+    if CFG["bias"]:
+        for nb in range(nbw):
+            e.ins(f"buffer_load_ushort {v(RM.BIASA + 4 * nb)}, {o('bias_voff')}, {s(RM.S_BRS, 4)}, 0 offen offset:{nb * 64}")
+            e._vm(None)
+            for k in range(1, 4):
+                e.ins(f"v_mov_b32 {v(RM.BIASA + 4 * nb + k)}, 0")
+        e.ins(f"v_mov_b32 {v(RM.ONES)}, {o('ones0')}")
+        for k in range(1, 4):
+            e.ins(f"v_mov_b32 {v(RM.ONES + k)}, 0")
+
+
+def tile_operand_finish(e, nbw):
+    """NORMAL-before-last step, behind its boundary: gate -> fp32 (G), and the rank-1 bias product acc += bias (x) ones"""
+    if CFG["res"]:
+        for nbp in range(nbw // 2):
+            for d in range(4):
+                e.ins(f"v_lshlrev_b32 {v(RM.G + 8 * nbp + 2 * d)}, 16, {v(RM.GRAW + 4 * nbp + d)}")
+                e.ins(f"v_and_b32 {v(RM.G + 8 * nbp + 2 * d + 1)}, 0xffff0000, {v(RM.GRAW + 4 * nbp + d)}")
+
+
+def bias_mfmas(e, nbw):
+    return [lambda nb=nb, mb=mb: e.mfma(acc(nb, mb), RM.BIASA + 4 * nb, RM.ONES) for nb in range(nbw) for mb in range(4)]
+
+
+def step_normal(e, p, first, uid, vm_entry=0, next_last=False, nbw=4):
     """One k-step, sub-step major, consuming stage p.  Entry: the sub-step-0 fragments are in flight into buffer 0.
     first: the accumulators start here (C = 0 in sub-step 0).  vm_entry: vector-memory operations issued by the predecessor after
     ITS direct-to-LDS batch (they are younger than the batch this step waits for)."""
     buf = lambda b: ([b * 32 + nb * 4 for nb in range(4)], [b * 32 + 16 + mb * 4 for mb in range(4)])   # offsets in R
-    to_v = lambda offs: [RM.R0 + o for o in offs]
+    to_v = lambda offs: [RM.R0 + x for x in offs]
     for ks in range(4):
         fa, fb = (to_v(x) for x in buf(ks & 1))
         na, nb_ = (to_v(x) for x in buf((ks + 1) & 1))
+        pre = []
         if ks == 3:
             # boundary: my loads of the next k-step have landed, my reads of this stage are done -> barrier ->
             # the other stage may be read, this stage may be refilled
             e.ins(f"s_waitcnt vmcnt({vm_entry + e.vm_own}) lgkmcnt(0)")
-            e.lgkm = []
+            e.lgkm, e.vmq = [], []
             e.ins("s_barrier")
             # (the last-step layout lives in R[0:32) + R[64:80): clear of buffer 1 = R[32:64), which sub-step 3 is using)
-            nxt = last_entry_reads(e, 1 - p) if next_last else frag_read_fillers(e, 1 - p, 0, na, nb_)
+            nxt = last_entry_reads(e, 1 - p) if next_last else frag_read_fillers(e, 1 - p, 0, na, nb_, nbw)
             fillers, cap = glds_fillers(e, p, with_reads=nxt), 1
+            if next_last:            # (vmcnt(0) above: the tile's gate / bias loads, issued in its first step, have landed)
+                tile_operand_finish(e, nbw)
+                if CFG["bias"]:
+                    pre = bias_mfmas(e, nbw)
         else:
             e.wait_lgkm0()
-            fillers, cap = frag_read_fillers(e, p, ks + 1, na, nb_), 1
+            fillers, cap = frag_read_fillers(e, p, ks + 1, na, nb_, nbw), 1
             if ks == 0:          # the load cursor moves on behind the batch the step before issued (entry contract of every step)
                 fillers, cap = fillers + cursor_advance(e, uid), 3
-        mf = [lambda nb=nb, mb=mb: e.mfma(acc(nb, mb), fa[nb], fb[mb], zero=(first and ks == 0)) for nb in range(4) for mb in range(4)]
-        interleave(e, mf, fillers, cap=cap)
+                if first and (CFG["res"] or CFG["bias"]):
+                    fillers = fillers + [lambda: tile_operand_loads_emit(e, nbw)]
+        mf = [lambda nb=nb, mb=mb: e.mfma(acc(nb, mb), fa[nb], fb[mb], zero=(first and ks == 0)) for nb in range(nbw) for mb in range(4)]
+        interleave(e, pre + mf, fillers, cap=cap)
 
 
 def epilogue_E1(e, nbp, mb):
@@ -341,58 +434,91 @@ def epilogue_E1(e, nbp, mb):
     return ops
 
 
-def epilogue_E2(e):
-    """scratch -> ROW: 8 tokens x 64 features per pair of reads (a lane: 8 consecutive features of one token)"""
-    ops = []
-    for g in range(4):
+def epilogue_rows(e, nbp, mb, res16=None):
+    """the pair's 32 output rows in 4 groups of 8: scratch (fp32) [+ residual rows] -> registers (double-buffered) -> bf16
+    [out = residual + gate * value] -> 16-byte stores.  Loads of group g + 1 are requested before group g is converted.
+    res16: 16 free registers for the residual rows of ALL four groups, requested up front — the memory counter retires in issue
+    order, so a residual load issued behind a store is only usable once that store has been acknowledged by memory (microseconds):
+    requested up front the pair waits once for the PREVIOUS pair's stores instead of once per group (measured: + 39 us on out_proj
+    with one wait per group).  None: the 2 x 4 registers of RM.RES, two groups at a time."""
+    res_of = (lambda g: res16 + 4 * g) if res16 is not None else (lambda g: RM.RES + 4 * (g & 1))
+
+    def load(g):
+        b = g & 1
+        ops = []
+        if CFG["res"] and res16 is None:
+            ops.append(lambda: e.res_load(res_of(g), RM.S_SO + mb * 4 + g, nbp * 128))
         for h in range(2):
-            ops.append(lambda g=g, h=h: e.ds_read(RM.ROW + (2 * g + h) * 4, RM.SCRR, g * 2048 + h * 16))
-    return ops
+            ops.append(lambda h=h: e.ds_read(RM.ROW + 8 * b + 4 * h, RM.SCRR, g * 2048 + h * 16))
+        return ops
 
+    def conv(g):
+        b = g & 1
+        row, res, pk, t0, t1 = RM.ROW + 8 * b, res_of(g), RM.PK + 4 * b, RM.TMP, RM.TMP + 1
 
-def epilogue_F1(e, nbp, mb):
-    """ROW -> bf16 -> four 16-byte stores (8 output rows x 128 B each)"""
-    ops = []
-    for g in range(4):
-        def cv(g=g):
-            e.need(range(RM.ROW + 8 * g, RM.ROW + 8 * g + 8))
+        def run():
+            e.need(range(row, row + 8))
+            if CFG["res"]:
+                e.need_vm(range(res, res + 4))
             for d in range(4):
-                e.ins(f"v_cvt_pk_bf16_f32 {v(RM.PK + 4 * g + d)}, {v(RM.ROW + 8 * g + 2 * d)}, {v(RM.ROW + 8 * g + 2 * d + 1)}")
-        ops.append(cv)
-        ops.append(lambda g=g: e.store(RM.PK + 4 * g, RM.S_SO + mb * 4 + g, nbp * 128))
+                if CFG["res"]:
+                    gq = RM.G + 8 * nbp + 2 * d
+                    e.ins(f"v_lshlrev_b32 {v(t0)}, 16, {v(res + d)}")
+                    e.ins(f"v_and_b32 {v(t1)}, 0xffff0000, {v(res + d)}")
+                    e.ins(f"v_fma_f32 {v(t0)}, {v(gq)}, {v(row + 2 * d)}, {v(t0)}")
+                    e.ins(f"v_fma_f32 {v(t1)}, {v(gq + 1)}, {v(row + 2 * d + 1)}, {v(t1)}")
+                    e.ins(f"v_cvt_pk_bf16_f32 {v(pk + d)}, {v(t0)}, {v(t1)}")
+                else:
+                    e.ins(f"v_cvt_pk_bf16_f32 {v(pk + d)}, {v(row + 2 * d)}, {v(row + 2 * d + 1)}")
+        return [run, lambda: e.store(pk, RM.S_SO + mb * 4 + g, nbp * 128)]
+    ops = load(0) + load(1)
+    for g in range(4):
+        ops += conv(g)
+        if g + 2 < 4:
+            ops += load(g + 2)
     return ops
 
 
-def step_last(e, p, uid):
-    """Last k-step of a tile, block-pair major (pair s: token block s >> 1, feature blocks 2 (s & 1), 2 (s & 1) + 1), with the
-    epilogue of pair s - 1 / s - 2 in the gaps of pair s and the boundary (next stage ready / this stage free) before pair 2."""
+def residual_loads(e, nbp, mb, res16):
+    return [lambda g=g: e.res_load(res16 + 4 * g, RM.S_SO + mb * 4 + g, nbp * 128) for g in range(4)]
+
+
+def step_last(e, p, uid, nbw=4):
+    """Last k-step of a tile, block-pair major (pair = token block mb, feature blocks 2 nbp, 2 nbp + 1), with the epilogue of the pair
+    before in the gaps of every pair and the boundary (next stage ready / this stage free) a quarter of the way in."""
     LA, LB = last_LA, last_LB
+    nbps = nbw // 2
+    pairs = [(mb, nbp) for mb in range(4) for nbp in range(nbps)]
+    bpos = len(pairs) // 4                              # pair in front of which the boundary sits: 2 (wide), 1 (narrow)
     rd_a = lambda nbp: [lambda nbl=nbl, ks=ks: e.ds_read(LA(nbp, nbl, ks), RM.AADDR + p * 4 + ks, (2 * nbp + nbl) * 4096)
                         for ks in range(4) for nbl in range(2)]
     rd_b = lambda mb: [lambda ks=ks: e.ds_read(LB(mb, ks), RM.BADDR + p * 4 + ks, mb * 4096) for ks in range(4)]
     # entry: the 12 reads of last_entry_reads() are in flight (issued by the step before)
     e.lgkm = [set(range(LA(0, nbl, ks), LA(0, nbl, ks) + 4)) for ks in range(4) for nbl in range(2)] + \
              [set(range(LB(0, ks), LB(0, ks) + 4)) for ks in range(4)]
-    for sl in range(8):
-        mb, nbp = sl >> 1, sl & 1
+    # every remaining fragment read of this stage goes out before the boundary
+    rest = (rd_a(1) if nbps == 2 else []) + rd_b(1) + rd_b(2) + rd_b(3)
+    per = (len(rest) + bpos - 1) // bpos
+    for sl, (mb, nbp) in enumerate(pairs):
         fill = []
-        if sl == 0:
-            fill += rd_a(1) + rd_b(1)
-        if sl == 1:
-            fill += rd_b(2) + rd_b(3) + cursor_advance(e, uid)      # (pending from the batch the step before issued)
-        if sl >= 2:
-            fill += epilogue_F1(e, (sl - 2) & 1, (sl - 2) >> 1)
+        if sl < bpos:
+            fill += rest[sl * per:(sl + 1) * per]
+        if sl == bpos - 1:
+            fill += cursor_advance(e, uid)              # (pending from the batch the step before issued)
         if sl >= 1:
-            fill += epilogue_E1(e, (sl - 1) & 1, (sl - 1) >> 1) + epilogue_E2(e)
-        if sl == 2:
-            e.ins(f"s_waitcnt vmcnt({e.vm_own}) lgkmcnt(0)")      # (nothing of mine is younger than the awaited batch yet)
-            e.lgkm = []
+            pmb, pnbp = pairs[sl - 1]
+            # B fragments of token block 0 are dead once its pairs have issued: their 16 registers take the pair's residual rows
+            res16 = last_LB(0, 0) if (CFG["res"] and mb >= 1) else None
+            fill += (residual_loads(e, pnbp, pmb, res16) if res16 is not None else []) + epilogue_E1(e, pnbp, pmb) + epilogue_rows(e, pnbp, pmb, res16)
+        if sl == bpos:
+            e.ins(f"s_waitcnt vmcnt({e.vm_own}) lgkmcnt(0)")      # (everything of mine so far is younger than the awaited batch)
+            e.lgkm, e.vmq = [], []
             e.ins("s_barrier")
-            fill = glds_fillers(e, p) + fill          # the whole batch FIRST: every store of this tile is younger than it
-        if sl == 7:
-            # sub-step-0 fragments of the next k-step (other stage) into buffer 0 = R[0:32): LA(0, ...) is free behind pair 6
+            fill = glds_fillers(e, p) + fill            # the batch first: the stores of the pairs from here on are younger than it
+        if sl == len(pairs) - 1:
+            # sub-step-0 fragments of the next k-step (other stage) into buffer 0 = R[0:32): LA(0, ...) is free behind the last pair
+            # of feature pair 0 (the wide layout: a narrow next tile simply ignores two of them)
             fill += frag_read_fillers(e, 1 - p, 0, [RM.R0 + nb * 4 for nb in range(4)], [RM.R0 + 16 + m * 4 for m in range(4)])
-        # this pair's fragments
         need = set()
         for ks in range(4):
             need |= set(range(LB(mb, ks), LB(mb, ks) + 4))
@@ -404,14 +530,52 @@ def step_last(e, p, uid):
             for nbl in range(2):
                 mf.append(lambda ks=ks, nbl=nbl: e.mfma(acc(2 * nbp + nbl, mb), LA(nbp, nbl, ks), LB(mb, ks)))
         interleave(e, mf, fill, first_gap=1 if sl >= 1 else 0)
-    for f in epilogue_F1(e, 0, 3) + epilogue_E1(e, 1, 3) + epilogue_E2(e) + epilogue_F1(e, 1, 3):
+    pmb, pnbp = pairs[-1]
+    res16 = last_LB(0, 0) if CFG["res"] else None
+    for f in (residual_loads(e, pnbp, pmb, res16) if res16 is not None else []) + epilogue_E1(e, pnbp, pmb) + epilogue_rows(e, pnbp, pmb, res16):
         f()
     return e.vm_after_glds
 
 
-def tile_advance(e, uid):
-    """compute cursor -> next tile of this workgroup, output descriptor of the wave tile"""
+def tile_descriptors():
+    """output (and residual) buffer descriptors, gate row pointer and bias descriptor of the wave tile the compute cursor is on;
+    sets S_CNARROW.  Contiguous scalar code (runs between tiles and in the prologue)."""
     T = RM.S_T
+    L = [f"s_mov_b32 {s(RM.S_CNARROW)}, 0"]
+    if CFG["narrow"]:
+        L += [f"s_cmp_eq_u32 {s(RM.S_CNT)}, {s(RM.S_NWIDE)}", f"s_cselect_b32 {s(RM.S_CNARROW)}, 1, 0"]
+    L += [
+        # rows: ((c_mt * 2 + wm) * 128) * out pitch;  columns (bytes): c_nt * 512 + wn * (256 wide | 128 narrow)
+        f"s_lshl_b32 {s(T)}, {s(RM.S_CMT)}, 1", f"s_add_u32 {s(T)}, {s(T)}, {s(RM.S_WM)}", f"s_lshl_b32 {s(T + 4)}, {s(T)}, 7",
+        f"s_mul_i32 {s(T)}, {s(T + 4)}, {s(RM.S_OP)}",
+        f"s_cmp_eq_u32 {s(RM.S_CNARROW)}, 1", f"s_cselect_b32 {s(T + 2)}, 7, 8", f"s_lshl_b32 {s(T + 2)}, {s(RM.S_WN)}, {s(T + 2)}",
+        f"s_lshl_b32 {s(T + 1)}, {s(RM.S_CNT)}, 9", f"s_add_u32 {s(T + 1)}, {s(T + 1)}, {s(T + 2)}",      # T1 = column byte offset
+        f"s_add_u32 {s(T)}, {s(T)}, {s(T + 1)}",
+        f"s_add_u32 {s(RM.S_RS)}, {s(RM.S_OUT)}, {s(T)}", f"s_addc_u32 {s(RM.S_RS + 1)}, {s(RM.S_OUT + 1)}, 0",
+        f"s_and_b32 {s(RM.S_RS + 1)}, {s(RM.S_RS + 1)}, 0xffff",
+        f"s_mov_b32 {s(RM.S_RS + 2)}, 0x7ffffffe", f"s_mov_b32 {s(RM.S_RS + 3)}, 0x00020000",
+    ]
+    if CFG["res"]:
+        L += [
+            f"s_add_u32 {s(RM.S_RRS)}, {o('res_lo')}, {s(T)}", f"s_addc_u32 {s(RM.S_RRS + 1)}, {o('res_hi')}, 0",
+            f"s_and_b32 {s(RM.S_RRS + 1)}, {s(RM.S_RRS + 1)}, 0xffff",
+            f"s_mov_b32 {s(RM.S_RRS + 2)}, 0x7ffffffe", f"s_mov_b32 {s(RM.S_RRS + 3)}, 0x00020000",
+            # gate row of the sample this wave tile lies in: sample = first row >> log2(rows per sample)
+            f"s_lshr_b32 {s(T + 2)}, {s(T + 4)}, {o('rpb_shift')}", f"s_mul_i32 {s(T + 2)}, {s(T + 2)}, {o('gate_bstride')}",
+            f"s_add_u32 {s(T + 2)}, {s(T + 2)}, {s(T + 1)}",
+            f"s_add_u32 {s(RM.S_GP)}, {o('gate_lo')}, {s(T + 2)}", f"s_addc_u32 {s(RM.S_GP + 1)}, {o('gate_hi')}, 0",
+        ]
+    if CFG["bias"]:
+        L += [
+            f"s_add_u32 {s(RM.S_BRS)}, {o('bias_lo')}, {s(T + 1)}", f"s_addc_u32 {s(RM.S_BRS + 1)}, {o('bias_hi')}, 0",
+            f"s_and_b32 {s(RM.S_BRS + 1)}, {s(RM.S_BRS + 1)}, 0xffff",
+            f"s_mov_b32 {s(RM.S_BRS + 2)}, 0x4000", f"s_mov_b32 {s(RM.S_BRS + 3)}, 0x00020000",
+        ]
+    return L
+
+
+def tile_advance(uid):
+    """compute cursor -> next tile of this workgroup, then its descriptors"""
     L = [
         f"s_add_u32 {s(RM.S_CMT)}, {s(RM.S_CMT)}, {s(RM.S_STM)}",
         f"s_add_u32 {s(RM.S_CNT)}, {s(RM.S_CNT)}, {s(RM.S_STN)}",
@@ -421,48 +585,43 @@ def tile_advance(e, uid):
         f"s_add_u32 {s(RM.S_CMT)}, {s(RM.S_CMT)}, 1",
         f"L_cnw_{uid}_%=:",
     ]
-    return L + out_descriptor()
+    return L + tile_descriptors()
 
 
-def out_descriptor():
-    T = RM.S_T
-    return [
-        # byte offset of the wave tile: ((c_mt * 2 + wm) * 128) * out pitch + ((c_nt * 2 + wn) * 128) * 2
-        f"s_lshl_b32 {s(T)}, {s(RM.S_CMT)}, 1", f"s_add_u32 {s(T)}, {s(T)}, {s(RM.S_WM)}", f"s_lshl_b32 {s(T)}, {s(T)}, 7",
-        f"s_mul_i32 {s(T)}, {s(T)}, {s(RM.S_OP)}",
-        f"s_lshl_b32 {s(T + 1)}, {s(RM.S_CNT)}, 1", f"s_add_u32 {s(T + 1)}, {s(T + 1)}, {s(RM.S_WN)}", f"s_lshl_b32 {s(T + 1)}, {s(T + 1)}, 8",
-        f"s_add_u32 {s(T)}, {s(T)}, {s(T + 1)}",
-        f"s_add_u32 {s(RM.S_RS)}, {s(RM.S_OUT)}, {s(T)}", f"s_addc_u32 {s(RM.S_RS + 1)}, {s(RM.S_OUT + 1)}, 0",
-        f"s_and_b32 {s(RM.S_RS + 1)}, {s(RM.S_RS + 1)}, 0xffff",
-        f"s_mov_b32 {s(RM.S_RS + 2)}, 0x7ffffffe", f"s_mov_b32 {s(RM.S_RS + 3)}, 0x00020000",
-    ]
-
-
-# operands of the asm statement: (constraint, C expression) in order; the body refers to them as %0 ...
+# operands of the asm statement: (constraint, C expression) in order; the body refers to them as %0 ...  Scalars that never change
+# arrive packed (the statement may have at most 30 operands); pointers of the epilogue operands as two halves (plain scalar sources).
 OPERANDS = [
     ("v", "voffw0"), ("v", "voffx0"), ("v", "a_base"), ("v", "b_base"), ("v", "t_xor"), ("v", "scrw_base"), ("v", "j7"),
-    ("v", "scrr"), ("v", "stoff"),
-    ("s", "w_ptr"), ("s", "x_ptr"), ("s", "out_ptr"), ("s", "w_pitch"), ("s", "x_pitch"), ("s", "o_pitch"), ("s", "nk"),
-    ("s", "tiles_n"), ("s", "my_tiles"), ("s", "step_m"), ("s", "step_n"), ("s", "mt0"), ("s", "nt0"), ("s", "wave"), ("s", "lds_base"),
+    ("v", "scrr"), ("v", "stoff"), ("v", "bias_voff"), ("v", "ones0"),
+    ("s", "w_ptr"), ("s", "x_ptr"), ("s", "out_ptr"), ("s", "w_pitch"), ("s", "x_pitch"), ("s", "o_pitch"),
+    ("s", "dims"),          # nk | tiles_n << 12 | n_wide << 22
+    ("s", "my_tiles"),
+    ("s", "steps"),         # step_m | step_n << 20
+    ("s", "tile0"),         # mt0 | nt0 << 20
+    ("s", "wave_lds"),      # LDS base (a multiple of 1024) + wave
+    ("s", "res_lo"), ("s", "res_hi"), ("s", "gate_lo"), ("s", "gate_hi"), ("s", "gate_bstride"), ("s", "rpb_shift"),
+    ("s", "bias_lo"), ("s", "bias_hi"),
 ]
+assert len(OPERANDS) <= 30
 OP = {name: i for i, (_, name) in enumerate(OPERANDS)}
 
 
 def prologue(e):
     e.in_prologue = True
-    o = lambda name: f"%{OP[name]}"
     T, TV = RM.S_T, RM.TMP
     L = []
-    # scalar state
     for dst, src in ((RM.S_W, "w_ptr"), (RM.S_X, "x_ptr"), (RM.S_OUT, "out_ptr")):
         L.append(f"s_mov_b64 {s(dst, 2)}, {o(src)}")
-    for dst, src in ((RM.S_WP, "w_pitch"), (RM.S_XP, "x_pitch"), (RM.S_OP, "o_pitch"), (RM.S_NK, "nk"), (RM.S_TN, "tiles_n"),
-                     (RM.S_TLEFT, "my_tiles"), (RM.S_STM, "step_m"), (RM.S_STN, "step_n"), (RM.S_LMT, "mt0"), (RM.S_LNT, "nt0"),
-                     (RM.S_CMT, "mt0"), (RM.S_CNT, "nt0")):
+    for dst, src in ((RM.S_WP, "w_pitch"), (RM.S_XP, "x_pitch"), (RM.S_OP, "o_pitch"), (RM.S_TLEFT, "my_tiles")):
         L.append(f"s_mov_b32 {s(dst)}, {o(src)}")
-    L += [f"s_mov_b32 {s(RM.S_LLEFT)}, {s(RM.S_TLEFT)}", f"s_mov_b32 {s(RM.S_LKT)}, {s(RM.S_NK)}",
-          f"s_and_b32 {s(RM.S_WN)}, {o('wave')}, 1", f"s_lshr_b32 {s(RM.S_WM)}, {o('wave')}, 1",
-          f"s_lshl_b32 {s(RM.S_LDSW)}, {o('wave')}, 10", f"s_add_u32 {s(RM.S_LDSW)}, {s(RM.S_LDSW)}, {o('lds_base')}"]
+    L += [f"s_and_b32 {s(RM.S_NK)}, {o('dims')}, 0xfff", f"s_lshr_b32 {s(RM.S_TN)}, {o('dims')}, 12", f"s_and_b32 {s(RM.S_TN)}, {s(RM.S_TN)}, 0x3ff",
+          f"s_lshr_b32 {s(RM.S_NWIDE)}, {o('dims')}, 22",
+          f"s_and_b32 {s(RM.S_STM)}, {o('steps')}, 0xfffff", f"s_lshr_b32 {s(RM.S_STN)}, {o('steps')}, 20",
+          f"s_and_b32 {s(RM.S_LMT)}, {o('tile0')}, 0xfffff", f"s_lshr_b32 {s(RM.S_LNT)}, {o('tile0')}, 20",
+          f"s_mov_b32 {s(RM.S_CMT)}, {s(RM.S_LMT)}", f"s_mov_b32 {s(RM.S_CNT)}, {s(RM.S_LNT)}",
+          f"s_mov_b32 {s(RM.S_LLEFT)}, {s(RM.S_TLEFT)}", f"s_mov_b32 {s(RM.S_LKT)}, {s(RM.S_NK)}",
+          f"s_and_b32 {s(T)}, {o('wave_lds')}, 3", f"s_and_b32 {s(RM.S_WN)}, {s(T)}, 1", f"s_lshr_b32 {s(RM.S_WM)}, {s(T)}, 1",
+          f"s_lshl_b32 {s(RM.S_LDSW)}, {s(T)}, 10", f"s_and_b32 {s(T)}, {o('wave_lds')}, 0xfffffc00", f"s_add_u32 {s(RM.S_LDSW)}, {s(RM.S_LDSW)}, {s(T)}"]
     for mb in range(4):
         for g in range(4):
             L += [f"s_mul_i32 {s(RM.S_SO + mb * 4 + g)}, {s(RM.S_OP)}, {mb * 32 + g * 8}"]
@@ -471,11 +630,12 @@ def prologue(e):
           f"s_add_u32 {s(RM.S_LW)}, {s(RM.S_W)}, {s(T)}", f"s_addc_u32 {s(RM.S_LW + 1)}, {s(RM.S_W + 1)}, 0",
           f"s_lshl_b32 {s(T)}, {s(RM.S_LMT)}, 8", f"s_mul_i32 {s(T)}, {s(T)}, {s(RM.S_XP)}",
           f"s_add_u32 {s(RM.S_LX)}, {s(RM.S_X)}, {s(T)}", f"s_addc_u32 {s(RM.S_LX + 1)}, {s(RM.S_X + 1)}, 0"]
-    L += out_descriptor()
+    L += tile_descriptors()
     # per-lane tables
     for i in range(8):
         L += [f"s_mul_i32 {s(T)}, {s(RM.S_WP)}, {i * 32}", f"v_add_u32 {v(RM.VOFFW + i)}, {s(T)}, {o('voffw0')}",
               f"s_mul_i32 {s(T)}, {s(RM.S_XP)}, {i * 32}", f"v_add_u32 {v(RM.VOFFX + i)}, {s(T)}, {o('voffx0')}"]
+    L += [t.replace("@", "pro") for t in voffwe_update()]
     for ks in range(4):
         L += [f"v_xor_b32 {v(TV)}, {ks * 2}, {o('t_xor')}", f"v_lshlrev_b32 {v(TV)}, 4, {v(TV)}",
               f"v_add_u32 {v(RM.AADDR + ks)}, {v(TV)}, {o('a_base')}", f"v_add_u32 {v(RM.BADDR + ks)}, {v(TV)}, {o('b_base')}",
@@ -484,7 +644,7 @@ def prologue(e):
         L += [f"v_xor_b32 {v(TV)}, {bq}, {o('j7')}", f"v_lshlrev_b32 {v(TV)}, 5, {v(TV)}", f"v_add_u32 {v(RM.SCRW + bq)}, {v(TV)}, {o('scrw_base')}"]
     L += [f"v_mov_b32 {v(RM.SCRR)}, {o('scrr')}", f"v_mov_b32 {v(RM.STOFF)}, {o('stoff')}"]
     for t in L:
-        e.ins(t)
+        (e.raw if t.endswith(":") else e.ins)(t)
     # k-steps 0 and 1 of the first tile in flight, the first one waited for, its sub-step-0 fragments requested
     for st in range(2):
         for f in glds_fillers(e, st) + (cursor_advance(e, f"pro{st}") if st == 0 else []):
@@ -498,12 +658,15 @@ def prologue(e):
 
 def clobbers():
     c = ["memory", "scc", "vcc"]
-    c += [f"v{i}" for i in range(32, 256)] + [f"a{i}" for i in range(256)] + [f"s{i}" for i in range(36, 96)]
+    c += [f"v{i}" for i in range(32, 256)] + [f"a{i}" for i in range(256)] + [f"s{i}" for i in range(36, 102)]
     return c
 
 
-def generate():
+def generate(cfg=None):
     """-> (asm text with %N operands and %= label ids, T = vector-memory ops a LAST step issues behind its direct-to-LDS batch)"""
+    global CFG
+    CFG = dict(narrow=False, res=False, bias=False)
+    CFG.update(cfg or {})
     out = []
 
     def block(fn, *args, **kw):
@@ -512,34 +675,43 @@ def generate():
         out.extend(e.lines)
         return r
 
-    # T: fixed point of "what a LAST step leaves behind its batch" (does not depend on the wait counts)
-    probe = Emit()
-    T_after = step_last(probe, 0, "probe")
+    widths = [4, 2] if CFG["narrow"] else [4]
+    # what a LAST step leaves behind its batch (does not depend on the wait counts); the next tile's FIRST step may follow either width
+    T_after = min(step_last(Emit(), 0, "probe", nbw=w) for w in widths)
     block(prologue)
+    tag = lambda w: "w" if w == 4 else "n"
+
+    def goto_by_width(prefix, q):
+        """branch to `prefix`_{w|n}_q by the width of the compute tile"""
+        if not CFG["narrow"]:
+            return [f"s_branch {prefix}_w_{q}_%="]
+        return [f"s_cmp_eq_u32 {s(RM.S_CNARROW)}, 1", f"s_cbranch_scc1 {prefix}_n_{q}_%=", f"s_branch {prefix}_w_{q}_%="]
+
     # control flow (nk >= 3): FIRST -> NORMAL x (nk - 3) -> NORMAL-before-last -> LAST, stage parity alternating; LAST -> FIRST
-    out.append("s_branch L_first0_%=")
-    for p in range(2):
-        q = 1 - p
-        variants = [(f"L_first_{p}", True, T_after, False), (f"L_norm_{p}", False, 0, False), (f"L_norml_{p}", False, 0, True)]
-        if p == 0:
-            variants.append(("L_first0", True, 0, False))
-        for name, first, vm_entry, next_last in variants:
-            out.append(f"{name}_%=:")
-            block(step_normal, p, first, name[2:], vm_entry=vm_entry, next_last=next_last)
-            if next_last:
-                out += [f"s_branch L_last_{q}_%="]
-                continue
-            if first:
-                out += [f"s_sub_u32 {s(RM.S_KCNT)}, {s(RM.S_NK)}, 2"]
-            else:
-                out += [f"s_sub_u32 {s(RM.S_KCNT)}, {s(RM.S_KCNT)}, 1"]
-            out += [f"s_cmp_eq_u32 {s(RM.S_KCNT)}, 1", f"s_cbranch_scc1 L_norml_{q}_%=", f"s_branch L_norm_{q}_%="]
-        out.append(f"L_last_{p}_%=:")
-        t_here = block(step_last, p, f"last{p}")
-        assert t_here == T_after
-        out += [f"s_sub_u32 {s(RM.S_TLEFT)}, {s(RM.S_TLEFT)}, 1", f"s_cmp_eq_u32 {s(RM.S_TLEFT)}, 0", f"s_cbranch_scc1 L_end_%="]
-        out += tile_advance(None, f"ta{p}")
-        out += [f"s_branch L_first_{q}_%="]
+    out += goto_by_width("L_first0", 0)
+    for w in widths:
+        for p in range(2):
+            q = 1 - p
+            variants = [(f"L_first_{tag(w)}_{p}", True, T_after, False), (f"L_norm_{tag(w)}_{p}", False, 0, False),
+                        (f"L_norml_{tag(w)}_{p}", False, 0, True)]
+            if p == 0:
+                variants.append((f"L_first0_{tag(w)}_0", True, 0, False))
+            for name, first, vm_entry, next_last in variants:
+                out.append(f"{name}_%=:")
+                block(step_normal, p, first, name[2:], vm_entry=vm_entry, next_last=next_last, nbw=w)
+                if next_last:
+                    out += [f"s_branch L_last_{tag(w)}_{q}_%="]
+                    continue
+                if first:
+                    out += [f"s_sub_u32 {s(RM.S_KCNT)}, {s(RM.S_NK)}, 2"]
+                else:
+                    out += [f"s_sub_u32 {s(RM.S_KCNT)}, {s(RM.S_KCNT)}, 1"]
+                out += [f"s_cmp_eq_u32 {s(RM.S_KCNT)}, 1", f"s_cbranch_scc1 L_norml_{tag(w)}_{q}_%=", f"s_branch L_norm_{tag(w)}_{q}_%="]
+            out.append(f"L_last_{tag(w)}_{p}_%=:")
+            block(step_last, p, f"last{tag(w)}{p}", nbw=w)
+            out += [f"s_sub_u32 {s(RM.S_TLEFT)}, {s(RM.S_TLEFT)}, 1", f"s_cmp_eq_u32 {s(RM.S_TLEFT)}, 0", f"s_cbranch_scc1 L_end_%="]
+            out += tile_advance(f"ta{tag(w)}{p}")
+            out += goto_by_width("L_first", q)
     out += ["L_end_%=:", "s_waitcnt vmcnt(0) lgkmcnt(0)"]
     return out, T_after
 
@@ -547,27 +719,30 @@ def generate():
 PROBE_VARIANTS = {"NOMFMA": {"nomfma"}, "LOADS": {"nomfma", "noreads", "nostore"}, "NOGLDS": {"noglds"}, "NOSTORE": {"nostore"},
                   "MFMAONLY": {"noglds", "nostore"},
                   "NOGLDS_LAX": {"noglds", "laxvm"}, "MFMA_NOEPI": {"noglds", "nostore", "noepi"}}
+# kernel variants: name -> what the body supports
+VARIANTS = {"": dict(), "_N": dict(narrow=True), "_NR": dict(narrow=True, res=True), "_NRB": dict(narrow=True, res=True, bias=True)}
 
 
 def emit_inc(path):
     global OPTS
     with open(path, "w") as fh:
         fh.write("// GENERATED by zigma_amd/csrc/gen/linear4w_gen.py --emit — do not edit (tests/test_linear4w_gen.py checks it is current).\n")
-        fh.write("// The main loop of linear4w_kernel as one asm statement; operands in the order of OPERANDS in the generator.\n")
+        fh.write("// The main loop of linear4w_kernel as one asm statement per variant; operands in the order of OPERANDS in the generator.\n")
 
-        def body(name, opts):
+        def body(name, cfg, opts=()):
             global OPTS
             OPTS = set(opts)
-            lines, _ = generate()
+            lines, _ = generate(cfg)
             OPTS = set()
             fh.write(f"#define ZIGMA_LINEAR4W_BODY{name} \\\n")
             for ln in lines:
                 fh.write(f'    "{ln}\\n" \\\n')
             fh.write("    \"\"\n")
-        body("", ())
+        for name, cfg in VARIANTS.items():
+            body(name, cfg)
         fh.write("#ifdef ZIGMA_LINEAR4W_PROBES   // timing probes (tools/linear4w_probe.py builds its own library with them): results are wrong\n")
         for name, opts in PROBE_VARIANTS.items():
-            body("_" + name, opts)
+            body("_" + name, {}, opts)
         fh.write("#endif\n")
         fh.write("#define ZIGMA_LINEAR4W_OPERANDS(" + ", ".join(n for _, n in OPERANDS) + ") \\\n    " +
                  ", ".join(f'"{c}"({n})' for c, n in OPERANDS) + "\n")
@@ -586,9 +761,10 @@ if __name__ == "__main__":
     if args.emit:
         emit_inc(os.path.join(os.path.dirname(HERE), "linear4w_body.inc"))
     if args.stats:
-        lines, T = generate()
-        n = sum(1 for l in lines if not l.endswith(":"))
-        print(f"{n} instructions, {sum('v_mfma' in l for l in lines)} MFMAs, T = {T}")
+        for name, cfg in VARIANTS.items():
+            lines, T = generate(cfg)
+            n = sum(1 for l in lines if not l.endswith(":"))
+            print(f"variant '{name}': {n} instructions, {sum('v_mfma' in l for l in lines)} MFMAs, T = {T}")
     if args.check:
         sys.path.insert(0, HERE)
         import linear4w_sim

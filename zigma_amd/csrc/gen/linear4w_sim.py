@@ -302,6 +302,32 @@ class Wave:
                 arr[o:o + 16] = np.ascontiguousarray(data[l]).view(np.uint8)
                 self.sh["stored"][base + off] = self.sh["stored"].get(base + off, 0) + 1
             self.vm.append(("store", None))
+        elif op in ("buffer_load_dwordx4", "buffer_load_ushort", "global_load_dwordx4"):
+            d = self.rng(args[0])
+            nreg, nbytes = (4, 16) if op.endswith("dwordx4") else (1, 2)
+            self.chk_v(d[1], nreg, text)
+            voff = self.rv(args[1]).astype(np.int64)
+            if op.startswith("buffer"):
+                rs = self.rng(args[2])
+                base = int(self.S[rs[1]]) | ((int(self.S[rs[1] + 1]) & 0xFFFF) << 32)
+                nrec = int(self.S[rs[1] + 2])
+                soff = self.rs(args[3])
+            else:
+                base, nrec, soff = self.rs64(args[2]), 1 << 62, 0
+            data = np.zeros((64, 4), np.uint32)
+            for l in range(64):
+                off = int(voff[l]) + soff + self.imm(text)
+                if off + nbytes > nrec:
+                    continue                                  # out of range: 0
+                arr, o_ = self.mem.find(base + off, nbytes)
+                if nbytes == 16:
+                    data[l] = np.ascontiguousarray(arr[o_:o_ + 16]).view(np.uint32)
+                else:
+                    data[l, 0] = int(arr[o_]) | (int(arr[o_ + 1]) << 8)
+            for k in range(nreg):
+                self.V[d[1] + k] = data[:, k]
+                self.vpend[d[1] + k] = f"`{text}`"
+            self.vm.append(("load", list(range(d[1], d[1] + nreg))))
         else:
             raise SimError(f"unknown instruction `{text}`")
         return False
@@ -318,6 +344,9 @@ class Wave:
 
     def retire_vm(self, ent):
         kind, grans = ent
+        if kind == "load":
+            for r in grans:
+                self.vpend.pop(r, None)
         if kind == "glds":
             for g in grans:
                 if self.sh["dma"].get(g) == self.wid:
@@ -446,24 +475,38 @@ def lane_operands(wave, w_pitch, x_pitch, o_pitch, lds_base=0):
         j7=j & 7,
         scrr=lds_base + 2 * 65536 + wave * 8192 + t8 * 256 + ((u ^ t8) << 5),
         stoff=t8 * o_pitch + u * 16,
+        bias_voff=np.where(lane < 32, j * 2, 0x7FFF0000),
+        ones0=np.where(lane < 32, 0x3F80, 0),
     )
 
 
-def simulate(M, N, K, n_wg=1, wg=0, seed=0, order=(0, 1, 2, 3), gen=None):
+def simulate(M, N, K, n_wg=8, wg=0, seed=0, order=(0, 1, 2, 3), gen=None, cfg=None, rows_per_batch=256):
     """one workgroup `wg` of `n_wg` (grid semantics of the launcher: a multiple of 8 workgroups, XCD-chunked tile lists); returns
-    (out as float32 (M, N), mask of the rows/cols this workgroup owns, reference)"""
+    (out as float32 (M, N), mask of what this workgroup owns, float64 reference, waves)"""
     import linear4w_gen as G
-    lines, _ = gen or G.generate()
+    cfg = dict(cfg or {})
+    lines, _ = gen or G.generate(cfg)
+    res_on, bias_on = bool(cfg.get("res")), bool(cfg.get("bias"))
     rng = np.random.default_rng(seed)
-    x = f32_to_bf16(rng.standard_normal((M, K)).astype(np.float32)).astype(np.uint16)
-    w = f32_to_bf16((rng.standard_normal((N, K)) * K ** -0.5).astype(np.float32)).astype(np.uint16)
+    rb = lambda a: f32_to_bf16(a.astype(np.float32)).astype(np.uint16)
+    x = rb(rng.standard_normal((M, K)))
+    w = rb(rng.standard_normal((N, K)) * K ** -0.5)
+    nb_ = M // rows_per_batch
+    res = rb(rng.standard_normal((M, N)))
+    gate = rb(rng.standard_normal((nb_, N)))
+    bias = rb(rng.standard_normal(N) * 0.5)
     out = np.full((M, N), 0x7FC0, np.uint16)            # NaN pattern: untouched outputs show
     mem = Memory()
-    WB, XB, OB = 0x10000000, 0x20000000, 0x40000000
+    WB, XB, OB, RB, GB, BB = 0x10000000, 0x20000000, 0x40000000, 0x60000000, 0x70000000, 0x78000000
     mem.add(WB, w.view(np.uint8).reshape(-1))
     mem.add(XB, x.view(np.uint8).reshape(-1))
     mem.add(OB, out.view(np.uint8).reshape(-1), writable=True)
-    tiles_m, tiles_n = M // 256, N // 256
+    mem.add(RB, res.view(np.uint8).reshape(-1))
+    mem.add(GB, gate.view(np.uint8).reshape(-1))
+    mem.add(BB, bias.view(np.uint8).reshape(-1))
+    tiles_m, n_wide, narrow = M // 256, N // 256, int(N % 256 != 0)
+    assert not narrow or cfg.get("narrow")
+    tiles_n = n_wide + narrow
     n_tiles = tiles_m * tiles_n
     xcd, slot, wg_per_xcd = wg & 7, wg >> 3, n_wg >> 3
     chunk = (n_tiles + 7) >> 3
@@ -472,9 +515,12 @@ def simulate(M, N, K, n_wg=1, wg=0, seed=0, order=(0, 1, 2, 3), gen=None):
     if tile0 >= chunk_end:
         return None
     my_tiles = (chunk_end - tile0 + wg_per_xcd - 1) // wg_per_xcd
-    sc = dict(w_ptr=WB, x_ptr=XB, out_ptr=OB, w_pitch=K * 2, x_pitch=K * 2, o_pitch=N * 2, nk=K // 64, tiles_n=tiles_n,
-              my_tiles=my_tiles, step_m=wg_per_xcd // tiles_n, step_n=wg_per_xcd % tiles_n, mt0=tile0 // tiles_n, nt0=tile0 % tiles_n,
-              lds_base=0)
+    nk = K // 64
+    sc = dict(w_ptr=WB, x_ptr=XB, out_ptr=OB, w_pitch=K * 2, x_pitch=K * 2, o_pitch=N * 2,
+              dims=nk | (tiles_n << 12) | (n_wide << 22), my_tiles=my_tiles,
+              steps=(wg_per_xcd // tiles_n) | ((wg_per_xcd % tiles_n) << 20), tile0=(tile0 // tiles_n) | ((tile0 % tiles_n) << 20),
+              res_lo=RB & 0xFFFFFFFF, res_hi=RB >> 32, gate_lo=GB & 0xFFFFFFFF, gate_hi=GB >> 32, gate_bstride=N * 2,
+              rpb_shift=int(np.log2(rows_per_batch)), bias_lo=BB & 0xFFFFFFFF, bias_hi=BB >> 32)
 
     def operands_for_wave(wv):
         lo = lane_operands(wv, K * 2, K * 2, N * 2)
@@ -486,7 +532,7 @@ def simulate(M, N, K, n_wg=1, wg=0, seed=0, order=(0, 1, 2, 3), gen=None):
                 preset[("v", nv)] = lo[name]
                 nv += 1
             else:
-                val = wv if name == "wave" else sc[name]
+                val = (0 + wv) if name == "wave_lds" else sc[name]
                 if name.endswith("_ptr"):
                     toks.append(f"s[{ns}:{ns + 1}]")
                     preset[("s", ns)], preset[("s", ns + 1)] = val & 0xFFFFFFFF, val >> 32
@@ -499,25 +545,33 @@ def simulate(M, N, K, n_wg=1, wg=0, seed=0, order=(0, 1, 2, 3), gen=None):
         return toks, preset
 
     waves, shared = run_workgroup(lines, operands_for_wave, mem, order)
-    xf, wf = bf16_to_f32(x), bf16_to_f32(w)
-    ref = xf.astype(np.float64) @ wf.astype(np.float64).T
+    f = lambda a: bf16_to_f32(a).astype(np.float64)
+    val = f(x) @ f(w).T
+    if bias_on:
+        val = val + f(bias)[None, :]
+    ref = val
+    if res_on:
+        ref = f(res) + np.repeat(f(gate), rows_per_batch, axis=0) * val
     owned = np.zeros((M, N), bool)
     t = tile0
+    n_mfma = 0
     for _ in range(my_tiles):
         mt, nt = divmod(t, tiles_n)
-        owned[mt * 256:(mt + 1) * 256, nt * 256:(nt + 1) * 256] = True
+        wdt = 256 if nt < n_wide else 128
+        owned[mt * 256:(mt + 1) * 256, nt * 256:nt * 256 + wdt] = True
+        n_mfma += (wdt // 64) * 4 * (nk * 4 + (1 if bias_on else 0))           # per wave: blocks x (k-steps x 4 sub-steps [+ the bias product])
         t += wg_per_xcd
     dup = [a for a, c in shared["stored"].items() if c != 1]
     if dup:
         raise SimError(f"{len(dup)} output pieces stored more than once")
-    return bf16_to_f32(out), owned, ref, waves
+    return bf16_to_f32(out), owned, ref, waves, n_mfma
 
 
-def check(M, N, K, n_wg, wg, order=(0, 1, 2, 3), seed=0, gen=None):
-    r = simulate(M, N, K, n_wg, wg, seed, order, gen)
+def check(M, N, K, n_wg=8, wg=0, order=(0, 1, 2, 3), seed=0, gen=None, cfg=None, rows_per_batch=256):
+    r = simulate(M, N, K, n_wg, wg, seed, order, gen, cfg, rows_per_batch)
     if r is None:
         return None
-    out, owned, ref, waves = r
+    out, owned, ref, waves, n_mfma = r
     if np.isnan(out[owned]).any():
         raise SimError(f"{int(np.isnan(out[owned]).sum())} owned outputs were never written")
     if not np.isnan(out[~owned]).all():
@@ -526,20 +580,35 @@ def check(M, N, K, n_wg, wg, order=(0, 1, 2, 3), seed=0, gen=None):
     err = np.linalg.norm(got - want) / np.linalg.norm(want)
     if not err < 3e-3:
         raise SimError(f"rel err {err:.3e}")
-    want_mfma = int(owned.sum()) // (256 * 256) * (K // 64) * 64
     for wv in waves:
-        if wv.stats["mfma"] != want_mfma:
-            raise SimError(f"wave {wv.wid}: {wv.stats['mfma']} MFMAs, expected {want_mfma}")
+        if wv.stats["mfma"] != n_mfma:
+            raise SimError(f"wave {wv.wid}: {wv.stats['mfma']} MFMAs, expected {n_mfma}")
     return err, waves[0].stats
+
+
+CASES = [
+    # (M, N, K, n_wg, wg, order, cfg, rows_per_batch)
+    (256, 256, 192, 8, 0, (0, 1, 2, 3), {}, 256),                                  # one tile, three k-steps
+    (1024, 768, 192, 8, 0, (3, 2, 1, 0), {}, 256),                                 # two tiles, odd k-step count: stage parity alternates
+    (1024, 768, 320, 8, 1, (0, 1, 2, 3), {}, 256),                                 # tile list wraps to the next m-tile; plain NORMAL steps
+    (4096, 512, 192, 16, 9, (0, 1, 2, 3), {}, 256),                                # two workgroups per XCD: tile stride 2
+    (512, 640, 256, 8, 0, (0, 1, 2, 3), dict(narrow=True), 256),                   # N = 640: wide, wide, narrow per m-tile; this one: wide
+    (512, 640, 256, 8, 2, (1, 3, 0, 2), dict(narrow=True), 256),                   # ... the narrow tile of m-tile 0 (first tile narrow)
+    (1024, 640, 192, 8, 1, (0, 1, 2, 3), dict(narrow=True), 256),                  # wide -> narrow inside one workgroup (chunk of 2)
+    (1024, 640, 192, 8, 2, (3, 2, 1, 0), dict(narrow=True), 256),                  # narrow -> wide ... 
+    (1024, 384, 320, 8, 0, (0, 1, 2, 3), dict(narrow=True, res=True), 512),        # gated residual, samples of 512 rows
+    (1024, 640, 192, 8, 1, (2, 0, 3, 1), dict(narrow=True, res=True), 256),        # ... across a wide -> narrow change
+    (512, 640, 256, 8, 2, (0, 1, 2, 3), dict(narrow=True, res=True, bias=True), 256),   # + bias (to_out)
+    (1024, 640, 192, 8, 1, (0, 1, 2, 3), dict(narrow=True, res=True, bias=True), 512),
+]
 
 
 def main():
     import time
-    for (M, N, K, n_wg, wg, order) in ((256, 256, 192, 8, 0, (0, 1, 2, 3)), (1024, 768, 192, 8, 0, (3, 2, 1, 0)), (1024, 768, 320, 8, 1, (0, 1, 2, 3)),
-                                       (512, 256, 256, 8, 1, (1, 3, 0, 2)), (4096, 512, 192, 16, 9, (0, 1, 2, 3))):
+    for (M, N, K, n_wg, wg, order, cfg, rpb) in CASES:
         t0 = time.time()
-        r = check(M, N, K, n_wg, wg, order)
-        print(f"M={M} N={N} K={K} wg {wg}/{n_wg} order {order}: {r and (f'rel err {r[0]:.2e}', r[1])}  ({time.time() - t0:.1f} s)")
+        r = check(M, N, K, n_wg, wg, order, cfg=cfg, rows_per_batch=rpb)
+        print(f"M={M} N={N} K={K} wg {wg}/{n_wg} {cfg} rpb {rpb}: {r and (f'rel err {r[0]:.2e}', r[1])}  ({time.time() - t0:.1f} s)")
 
 
 if __name__ == "__main__":

@@ -373,16 +373,16 @@ extern "C" int zigma_linear_fwd(const zigma_linear_params_t *pp, void *stream_) 
         (reinterpret_cast<uintptr_t>(p.x) | reinterpret_cast<uintptr_t>(p.w)) % 16 != 0 || reinterpret_cast<uintptr_t>(p.out) % 8 != 0)
         return ZIGMA_ERR_STRIDE;
     hipStream_t stream = static_cast<hipStream_t>(stream_);
-    if (linear4w_eligible(p)) return launch_linear4w(p, stream);        // (needs flags == 0: any probe flag pins the 8-wave kernel)
     const int tiles_m = static_cast<int>((p.m + kLinBM - 1) / kLinBM);
-    if (p.residual) {                     // gated residual epilogue: the 256 x 128 tile kernel
+    if (p.residual) {                     // gated residual epilogue
         if (!p.gate || p.rows_per_batch < 1 || p.rows_per_batch % 256 != 0 || p.m % p.rows_per_batch != 0) return ZIGMA_ERR_SHAPE;
         if (p.res_row_stride % 8 != 0 || p.gate_batch_stride % 8 != 0 || reinterpret_cast<uintptr_t>(p.residual) % 16 != 0 ||
             reinterpret_cast<uintptr_t>(p.gate) % 16 != 0 || 256 * p.res_row_stride * 2 > 0x7fffffff)
             return ZIGMA_ERR_STRIDE;
     }
-    const bool wide = p.n % 256 == 0 && !(p.flags & 0x1000) && !p.residual;      // 0x1000: force the 256 x 128 tile (probe)
     if (p.bias && (p.n > 4096 || reinterpret_cast<uintptr_t>(p.bias) % 4 != 0)) return ZIGMA_ERR_SHAPE;
+    if (linear4w_eligible(p)) return launch_linear4w(p, stream);        // (needs flags == 0: any probe flag pins the 8-wave kernel)
+    const bool wide = p.n % 256 == 0 && !(p.flags & 0x1000) && !p.residual;      // 0x1000: force the 256 x 128 tile (probe)
     const int tiles_n = p.n / (wide ? 256 : 128);
     const int64_t n_tiles = static_cast<int64_t>(tiles_m) * tiles_n;
     if (n_tiles > 0x7fffffff) return ZIGMA_ERR_SHAPE;

@@ -19,7 +19,7 @@ LINEAR_POLICY = os.environ.get("ZIGMA_LINEAR", "auto")
 
 def routes_to_4w(m, n, k, bias=None):
     """shapes zigma_linear_fwd serves with the one-wave-per-SIMD kernel (csrc/linear4w.hip): the wide epilogue-free projections"""
-    return bias is None and m % 256 == 0 and n % 256 == 0 and k % 64 == 0 and k >= 192 and (m // 256) * (n // 256) >= 256
+    return bias is None and m % 256 == 0 and n % 128 == 0 and k % 64 == 0 and k >= 192 and (m // 256) * ((n + 255) // 256) >= 256
 
 
 AUTO_4W_MAX_N = int(os.environ.get("ZIGMA_4W_MAX_N", "1024"))   # "auto": the 4-wave kernel where it at least ties the library (to_q; not in_proj)
