@@ -22,6 +22,7 @@ def routes_to_4w(m, n, k, bias=None):
     return bias is None and m % 256 == 0 and n % 128 == 0 and k % 64 == 0 and k >= 192 and (m // 256) * ((n + 255) // 256) >= 256
 
 
+FORCE_8W = os.environ.get("ZIGMA_LINEAR_8W", "0") == "1"      # A/B knob of tools/fwd_4w_ab.sh: pin the 8-wave kernel
 AUTO_4W_MAX_N = int(os.environ.get("ZIGMA_4W_MAX_N", "1024"))   # "auto": the 4-wave kernel where it at least ties the library (to_q; not in_proj)
 
 
@@ -63,7 +64,7 @@ def linear(x, weight, bias=None, silu_from_col=None, out=None, _probe_flags=0, r
         out = torch.empty(x2.shape[0], n, device=x.device, dtype=x.dtype)
     o2 = out if out.dim() == 2 else out.view(-1, n)            # a view: the kernel writes through the row pitch
     P = _lib.LinearParams()
-    P.m, P.n, P.k, P.dtype, P.flags = x2.shape[0], n, k, _lib.dtype_id(x), int(_probe_flags)
+    P.m, P.n, P.k, P.dtype, P.flags = x2.shape[0], n, k, _lib.dtype_id(x), int(_probe_flags) | (0x2000 if FORCE_8W else 0)
     P.silu_from_col = n if silu_from_col is None else int(silu_from_col)
     P.x_row_stride, P.w_row_stride, P.out_row_stride = x2.stride(0), weight.stride(0), o2.stride(0)
     P.x, P.w, P.bias, P.out = _lib.ptr(x2), _lib.ptr(weight), _lib.ptr(bias), _lib.ptr(o2)
