@@ -29,7 +29,8 @@ def run_sp(name):
 
 
 def run(name, env, zact=False):
-    fl = _lib.SCAN_PROBE_V1 if env == "v1" else (int(env[4:]) << _lib.SCAN_PROBE_PRIO_SHIFT) if env and env.startswith("prio") else 0
+    fl = _lib.SCAN_PROBE_V1 if env == "v1" else (int(env[4:]) << _lib.SCAN_PROBE_PRIO_SHIFT) if env and env.startswith("prio") else \
+        int(env[3:], 16) if env and env.startswith("raw") else 0
     y = outs.setdefault(name, torch.empty(B, L, Di, device=dev, dtype=dt))
     scan_raw(u.transpose(1, 2), delta.transpose(1, 2), A, Bv, Cv, D, xz[:, :, Di:].transpose(1, 2), None, False,
              out_z=y.transpose(1, 2), z_row_index=perm, out_row_index=perm, want_out=False, z_preactivated=zact, _probe_flags=fl)
@@ -37,7 +38,8 @@ def run(name, env, zact=False):
 
 
 variants = [("v1", "v1", False), ("v2", None, False), ("v2_zact", None, True), ("v2_softplus_inside", "SP", False)] + \
-           [("v2_no_prio_rotation", "prio1", False)]
+           [("v2_no_prio_rotation", "prio1", False), ("probe_no_barriers", "raw2000", False), ("probe_no_y_handover", "raw4000", False),
+            ("probe_neither", "raw6000", False)]
 _run = run
 run = lambda n, e, z=False: run_sp(n) if e == "SP" else _run(n, e, z)
 names = {n: run(n, e, z) for n, e, z in variants}
