@@ -15,7 +15,7 @@ agg = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in sorted(glob.glob("gpurun_out/pmc_pj_*/**/*counter_collection.csv", recursive=True)):
     for r in csv.DictReader(open(f)):
         n = r["Kernel_Name"]
-        if "Cijk" in n or "linear_tn" in n or "dt_proj" in n or "conv_x_proj" in n or "cross_attn" in n:
+        if "Cijk" in n or "linear4w" in n or "linear_tn" in n or "dt_proj" in n or "conv_x_proj" in n or "cross_attn" in n:
             key = n.split("(")[0][:60] if "Cijk" not in n else n[:70]
             agg[key][r["Counter_Name"]].append(float(r["Counter_Value"]))
 for k, c in sorted(agg.items(), key=lambda kv: -sum(kv[1].get("GRBM_GUI_ACTIVE", [0]))):
