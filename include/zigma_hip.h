@@ -27,11 +27,12 @@
 extern "C" {
 #endif
 
-#define ZIGMA_ABI_VERSION 5   /* 2: parameter blocks grew (row tables in the backward, checkpoints, reset_period)
+#define ZIGMA_ABI_VERSION 6   /* 2: parameter blocks grew (row tables in the backward, checkpoints, reset_period)
                                * 3: scan block: `info` out-field, ZIGMA_SCAN_Z_PREACTIVATED flag; zigma_linear_fwd
                                * 4: zigma_linear_params_t grew (gated residual epilogue); zigma_conv_x_proj_fwd, zigma_q_attn_fwd
                                * 5: pruned — zigma_q_attn_fwd and the dt product of zigma_conv_xproj_params_t removed (measured no faster,
-                               *    archived under tools/experiments/) */
+                               *    archived under tools/experiments/)
+                               * 6: zigma_cross_attn_bwd / zigma_cross_attn_bwd_chunks added */
 
 /* zigma_scan_params_t.flags */
 #define ZIGMA_SCAN_Z_PREACTIVATED 2   /* z already holds silu(z) (the in_proj GEMM epilogue applied it): out_z = y * z */
@@ -390,6 +391,32 @@ typedef struct zigma_xattn_params {
 } zigma_xattn_params_t;
 
 int zigma_cross_attn_fwd(const zigma_xattn_params_t *p, void *stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Backward of zigma_cross_attn_fwd (what autograd derives for the scaled_dot_product_attention call of the reference,
+ * model_zigma.py:113-127, when it trains; nothing of the forward is saved — the probabilities are recomputed):
+ *   dq (batch, seqlen, heads*head_dim) bf16;  dk_part, dv_part: fp32 partial sums, contiguous
+ *   (chunks, batch, n_ctx, heads*head_dim) with chunks = zigma_cross_attn_bwd_chunks(seqlen) — the caller adds the chunks
+ *   (deterministic: no atomics).  Same operand layout and limits as the forward; dout has the layout of out.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct zigma_xattn_bwd_params {
+    int32_t batch, seqlen, n_ctx, heads, head_dim;
+    int32_t dtype;
+    int32_t flags;   /* reserved, must be 0 */
+    float scale;
+    int32_t chunks;  /* zigma_cross_attn_bwd_chunks(seqlen) */
+    int32_t pad_;
+    int64_t q_batch_stride, q_row_stride;
+    int64_t k_batch_stride, k_row_stride;
+    int64_t v_batch_stride, v_row_stride;
+    int64_t do_batch_stride, do_row_stride;
+    int64_t dq_batch_stride, dq_row_stride;
+    const void *q, *k, *v, *dout;
+    void *dq, *dk_part, *dv_part;
+} zigma_xattn_bwd_params_t;
+
+int zigma_cross_attn_bwd_chunks(int seqlen);
+int zigma_cross_attn_bwd(const zigma_xattn_bwd_params_t *p, void *stream);
 
 /* ------------------------------------------------------------------------------------------
  * x_proj: out[m, n] = sum_k x[m, k] * w[n, k]  for the skinny projection of the Mamba block (n = dt_rank + 2 d_state).

@@ -110,6 +110,14 @@ class XAttnParams(C.Structure):
                 + [(n, vp) for n in ("q", "k", "v", "out")])
 
 
+class XAttnBwdParams(C.Structure):
+    _fields_ = ([(n, i32) for n in ("batch", "seqlen", "n_ctx", "heads", "head_dim", "dtype", "flags")] + [("scale", f32)]
+                + [("chunks", i32), ("pad_", i32)]
+                + [(n, i64) for n in ("q_batch_stride", "q_row_stride", "k_batch_stride", "k_row_stride", "v_batch_stride",
+                                      "v_row_stride", "do_batch_stride", "do_row_stride", "dq_batch_stride", "dq_row_stride")]
+                + [(n, vp) for n in ("q", "k", "v", "dout", "dq", "dk_part", "dv_part")])
+
+
 class GlueBwdParams(C.Structure):
     _fields_ = ([("rows", i64), ("cols", i32), ("rows_per_batch", i32), ("dtype", i32), ("flags", i32), ("s_add", f32), ("pad_", i32)]
                 + [(n, i64) for n in ("dy_row_stride", "a_row_stride", "out_row_stride", "s_batch_stride")]
@@ -137,7 +145,7 @@ EXPORTS = ("zigma_linear_fwd", "zigma_conv_x_proj_fwd", "zigma_scale_reduce_bwd"
            "zigma_selective_scan_bwd_workspace_bytes", "zigma_causal_conv1d_bwd",
            "zigma_causal_conv1d_bwd_workspace_bytes", "zigma_add_norm_bwd", "zigma_add_norm_bwd_workspace_bytes",
            "zigma_strerror",
-           "zigma_abi_version", "zigma_last_kernel")
+           "zigma_cross_attn_bwd", "zigma_cross_attn_bwd_chunks", "zigma_abi_version", "zigma_last_kernel")
 
 _lib = None
 
@@ -154,7 +162,7 @@ def lib():
         for name, st in (("zigma_selective_scan_fwd", ScanParams), ("zigma_causal_conv1d_fwd", ConvParams),
                          ("zigma_add_norm_fwd", NormParams), ("zigma_dt_proj_softplus_fwd", DtProjParams),
                          ("zigma_selective_scan_bwd", ScanBwdParams), ("zigma_causal_conv1d_bwd", ConvBwdParams),
-                         ("zigma_add_norm_bwd", NormBwdParams), ("zigma_cross_attn_fwd", XAttnParams), ("zigma_x_proj_fwd", XProjParams),
+                         ("zigma_add_norm_bwd", NormBwdParams), ("zigma_cross_attn_fwd", XAttnParams), ("zigma_cross_attn_bwd", XAttnBwdParams), ("zigma_x_proj_fwd", XProjParams),
                          ("zigma_linear_fwd", LinearParams), ("zigma_conv_x_proj_fwd", ConvXProjParams), ("zigma_scale_reduce_bwd", GlueBwdParams)):
             fn = getattr(L, name)
             fn.argtypes = [C.POINTER(st), vp]
@@ -165,11 +173,13 @@ def lib():
             fn = getattr(L, name)
             fn.argtypes = [C.POINTER(st)]
             fn.restype = C.c_int64
+        L.zigma_cross_attn_bwd_chunks.argtypes = [C.c_int]
+        L.zigma_cross_attn_bwd_chunks.restype = C.c_int
         L.zigma_strerror.argtypes = [C.c_int]
         L.zigma_strerror.restype = C.c_char_p
         L.zigma_abi_version.restype = C.c_int
         L.zigma_last_kernel.restype = C.c_char_p
-        if L.zigma_abi_version() != 5:
+        if L.zigma_abi_version() != 6:
             raise RuntimeError("zigma_amd: libzigma_hip.so ABI version mismatch")
         _lib = L
     return _lib

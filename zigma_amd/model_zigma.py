@@ -28,7 +28,7 @@ import torch.nn.functional as F
 import torch.utils.checkpoint
 from torch import Tensor
 
-from .attention import cross_attn, cross_attn_eligible
+from .attention import attention_math, cross_attn, cross_attn_eligible, cross_attn_train
 from .layernorm import RMSNorm, block_norm, glue_bwd_eligible, layer_norm_fn, rms_norm_fn, scale_reduce_bwd
 from .linear import gated_residual_eligible, linear, linear_eligible
 from .mamba_simple import Mamba
@@ -137,15 +137,14 @@ class CrossAttention(nn.Module):
         H = self.heads
         k, v = kv[:2] if kv is not None else (self.to_k(text), self.to_v(text))
         q = self._proj(x, self.to_q)
-        if not torch.is_grad_enabled() and cross_attn_eligible(q, k, v, H):
-            # HIP kernels: attention core in one pass (K/V of the head in LDS), to_out on the MFMA projection kernel
+        if cross_attn_eligible(q, k, v, H):
+            # HIP kernel: attention core in one pass (K/V of the head in LDS); under autograd its differentiable form (backward =
+            # library GEMMs + ATen elementwise ops).  No fused SDPA anywhere: on ROCm that is an AOT-Triton kernel.
+            if torch.is_grad_enabled() and (q.requires_grad or k.requires_grad or v.requires_grad):
+                return self._proj_out(cross_attn_train(q, k, v, H, self.scale), residual, gate)
             return self._proj_out(cross_attn(q, k, v, H, self.scale), residual, gate)
-        q = q.view(Bsz, L, H, -1).transpose(1, 2)
-        k = k.reshape(Bsz, k.shape[1], H, -1).transpose(1, 2)
-        v = v.reshape(Bsz, v.shape[1], H, -1).transpose(1, 2)
-        o = F.scaled_dot_product_attention(q, k, v)
-        out = self.to_out(o.transpose(1, 2).reshape(Bsz, L, -1))
-        return out if residual is None else torch.addcmul(residual, gate.unsqueeze(1), out)
+        # operands the kernel does not take (fp32 / fp16 models, CPU tensors, long contexts): the same math in torch ops
+        return self._proj_out(attention_math(q, k.reshape(Bsz, k.shape[1], -1), v.reshape(Bsz, v.shape[1], -1), H, self.scale), residual, gate)
 
 
 def drop_path(x, drop_prob: float = 0.0, training: bool = False, scale_by_keep: bool = True):
