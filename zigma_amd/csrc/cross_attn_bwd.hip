@@ -39,8 +39,8 @@ __device__ __forceinline__ f32x4 mfma16(s16x4 a, s16x4 b, f32x4 c) { return __bu
 
 constexpr int xb_max(int a, int b) { return a > b ? a : b; }
 
-template <int NKB>                       // 16-key blocks: n_ctx <= 16 * NKB
-__global__ __launch_bounds__(64 * kXbWaves) void cross_attn_bwd_kernel(const zigma_xattn_bwd_params_t p, const int tiles) {
+template <int NKB, int WPE, bool PF>     // 16-key blocks: n_ctx <= 16 * NKB; waves per SIMD the register budget is set for; operand prefetch
+__global__ __launch_bounds__(64 * kXbWaves) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void cross_attn_bwd_kernel(const zigma_xattn_bwd_params_t p, const int tiles) {
     constexpr int KP = 16 * NKB;
     constexpr int KTPitch = (KP + 8) * 2;                 // bytes per row of K^T
     constexpr int kOffV = KP * kXbRowPitch, kOffKT = 2 * KP * kXbRowPitch, kOffTile = kOffKT + kXbD * KTPitch;
@@ -101,26 +101,26 @@ __global__ __launch_bounds__(64 * kXbWaves) void cross_attn_bwd_kernel(const zig
         for (int nb = 0; nb < NKB; ++nb) dvt[blk][nb] = dkt[blk][nb] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     const int tile0 = blockIdx.x * tiles * kXbWaves + wave;          // this wave's tiles: tile0, tile0 + 4, ...
-    auto load_rows = [&](const uint16_t *base, int64_t row_stride, int t0, bool zero_tail, bf16x8 (&xa)[2]) {
+    auto load_rows = [&](const uint16_t *base, int64_t row_stride, int t0, uint4 (&xa)[2]) {
         const int tq = t0 + i16;                                     // lane -> token t0 + i16, features 32 ks + 8 g ..
         const uint16_t *row = base + static_cast<int64_t>(tq < L ? tq : L - 1) * row_stride;
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            uint4 w = *reinterpret_cast<const uint4 *>(row + ks * 32 + g * 8);
-            if (zero_tail && tq >= L) w = make_uint4(0, 0, 0, 0);    // dO = 0 for tokens past the end: no contribution to dK / dV
-            xa[ks] = __builtin_bit_cast(bf16x8, w);
-        }
+        for (int ks = 0; ks < 2; ++ks) xa[ks] = *reinterpret_cast<const uint4 *>(row + ks * 32 + g * 8);
     };
-    bf16x8 qn[2], dn[2];
-    if (tile0 * kXbTok < L) { load_rows(qb, p.q_row_stride, tile0 * kXbTok, false, qn); load_rows(gb, p.do_row_stride, tile0 * kXbTok, true, dn); }
+    uint4 qn[2], dn[2];
+    if (PF && tile0 * kXbTok < L) { load_rows(qb, p.q_row_stride, tile0 * kXbTok, qn); load_rows(gb, p.do_row_stride, tile0 * kXbTok, dn); }
 #pragma unroll 1
     for (int it = 0; it < tiles; ++it) {
         const int t0 = (tile0 + it * kXbWaves) * kXbTok;
         if (t0 >= L) break;                                          // wave-uniform; no workgroup barriers inside the loop
-        const bf16x8 qa[2] = {qn[0], qn[1]}, da[2] = {dn[0], dn[1]};
-        if (it + 1 < tiles && t0 + kXbWaves * kXbTok < L) {
-            load_rows(qb, p.q_row_stride, t0 + kXbWaves * kXbTok, false, qn);
-            load_rows(gb, p.do_row_stride, t0 + kXbWaves * kXbTok, true, dn);
+        if (!PF) { load_rows(qb, p.q_row_stride, t0, qn); load_rows(gb, p.do_row_stride, t0, dn); }
+        const bool tail = t0 + i16 >= L;                             // dO = 0 for tokens past the end: no contribution to dK / dV
+        const bf16x8 qa[2] = {__builtin_bit_cast(bf16x8, qn[0]), __builtin_bit_cast(bf16x8, qn[1])};
+        const bf16x8 da[2] = {__builtin_bit_cast(bf16x8, tail ? make_uint4(0, 0, 0, 0) : dn[0]),
+                              __builtin_bit_cast(bf16x8, tail ? make_uint4(0, 0, 0, 0) : dn[1])};
+        if (PF && it + 1 < tiles && t0 + kXbWaves * kXbTok < L) {
+            load_rows(qb, p.q_row_stride, t0 + kXbWaves * kXbTok, qn);
+            load_rows(gb, p.do_row_stride, t0 + kXbWaves * kXbTok, dn);
         }
         // ======== token in the lane: S^T, dP^T -> statistics, dS^T, dQ^T ========
         float m = -INFINITY, inv, delta = 0.f;
@@ -169,7 +169,7 @@ __global__ __launch_bounds__(64 * kXbWaves) void cross_attn_bwd_kernel(const zig
             for (int nb = 0; nb < NKB; ++nb) {
                 f32x4 ds;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) ds[r] = s[nb][r] * (dpt[nb][r] - delta) * scale;
+                for (int r = 0; r < 4; ++r) ds[r] = s[nb][r] * (dpt[nb][r] - delta);      // dS / scale
                 const s16x4 dsb = xb_pack4(ds);
 #pragma unroll
                 for (int db = 0; db < 4; ++db) {
@@ -181,7 +181,7 @@ __global__ __launch_bounds__(64 * kXbWaves) void cross_attn_bwd_kernel(const zig
 #pragma unroll
         for (int db = 0; db < 4; ++db)
             *reinterpret_cast<uint2 *>(tile + i16 * kXbRowPitch + (db * 16 + 4 * g) * 2) =
-                make_uint2(xb_pack(dq[db][0], dq[db][1]), xb_pack(dq[db][2], dq[db][3]));
+                make_uint2(xb_pack(dq[db][0] * scale, dq[db][1] * scale), xb_pack(dq[db][2] * scale, dq[db][3] * scale));
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -230,7 +230,7 @@ __global__ __launch_bounds__(64 * kXbWaves) void cross_attn_bwd_kernel(const zig
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 pr[r] = live ? fast_exp2(s[r] * sc2 - mB[r]) * invB[r] : 0.f;
-                ds[r] = pr[r] * (dp[r] - deltaB[r]) * scale;
+                ds[r] = pr[r] * (dp[r] - deltaB[r]);                  // dS / scale: dK^T is scaled once, in the reduction
             }
             const s16x4 pb = xb_pack4(pr), dsb = xb_pack4(ds);
 #pragma unroll
@@ -252,7 +252,7 @@ __global__ __launch_bounds__(64 * kXbWaves) void cross_attn_bwd_kernel(const zig
 #pragma unroll
                 for (int nb = 0; nb < NKB; ++nb) {
                     const int off = (nb * 16 + i16) * (kXbRedPitch / 4) + 32 * (blk >> 1) + 8 * g + 4 * (blk & 1);
-                    f32x4 ak = dkt[blk][nb], av = dvt[blk][nb];
+                    f32x4 ak = dkt[blk][nb] * scale, av = dvt[blk][nb];
                     if (w > 0) {
                         ak += *reinterpret_cast<const f32x4 *>(red_k + off);
                         av += *reinterpret_cast<const f32x4 *>(red_v + off);
@@ -305,8 +305,10 @@ extern "C" int zigma_cross_attn_bwd(const zigma_xattn_bwd_params_t *pp, void *st
     const int tiles = xb_tiles(p.seqlen);
     dim3 grid(p.chunks, p.heads, p.batch), block(64 * kXbWaves);
     hipStream_t stream = static_cast<hipStream_t>(stream_);
-    if (p.n_ctx <= 80) hipLaunchKernelGGL(cross_attn_bwd_kernel<5>, grid, block, 0, stream, p, tiles);
-    else hipLaunchKernelGGL(cross_attn_bwd_kernel<8>, grid, block, 0, stream, p, tiles);
+    // measured at B=64, L=1024, 8 heads, 77 keys (tools/attn_probe.py): 2 waves per SIMD without operand prefetch 147 us, with 194 us
+    // (45 spilled registers); 1 wave per SIMD 171 us without / 188 us with prefetch
+    if (p.n_ctx <= 80) hipLaunchKernelGGL((cross_attn_bwd_kernel<5, 2, false>), grid, block, 0, stream, p, tiles);
+    else hipLaunchKernelGGL((cross_attn_bwd_kernel<8, 1, false>), grid, block, 0, stream, p, tiles);
     set_last_kernel("cross_attn_bwd_mfma");
     return check_launch();
 }
