@@ -3,7 +3,15 @@ already softplus'ed by the dt_proj kernel, gate only, zigzag row tables): first-
 against scan_tok2_kernel, interleaved rounds in ONE process (cdna_hip_programming.md §5.4 rule 24), plus the
 z-preactivated variant (SiLU moved out of the kernel).  Prints one JSON line."""
 import json, os, sys, torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+PROBES = os.environ.get("PROBES") == "1"        # the no-barrier / no-hand-over timing probes live in a probe build (-DZIGMA_SCAN_PROBES)
+if PROBES:
+    PROBE_LIB = os.path.join(ROOT, "tools", "libzigma_scan_probes.so")
+    if not os.path.exists(PROBE_LIB):           # (build it in the container before the GPU call)
+        from zigma_amd import build as zbuild
+        zbuild.build(verbose=False, lib=PROBE_LIB, extra_flags=("-DZIGMA_SCAN_PROBES",))
+    os.environ["ZIGMA_AMD_LIB"] = PROBE_LIB
 from zigma_amd import _lib
 from zigma_amd.selective_scan_interface import scan_raw
 dev, dt = "cuda", torch.bfloat16
@@ -38,8 +46,8 @@ def run(name, env, zact=False):
 
 
 variants = [("v1", "v1", False), ("v2", None, False), ("v2_zact", None, True), ("v2_softplus_inside", "SP", False)] + \
-           [("v2_no_prio_rotation", "prio1", False), ("probe_no_barriers", "raw2000", False), ("probe_no_y_handover", "raw4000", False),
-            ("probe_neither", "raw6000", False)]
+           [("v2_no_prio_rotation", "prio1", False)] + \
+           ([("probe_no_barriers", "raw2000", False), ("probe_no_y_handover", "raw4000", False), ("probe_neither", "raw6000", False)] if PROBES else [])
 _run = run
 run = lambda n, e, z=False: run_sp(n) if e == "SP" else _run(n, e, z)
 names = {n: run(n, e, z) for n, e, z in variants}

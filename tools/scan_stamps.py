@@ -1,7 +1,13 @@
 """When does every workgroup of the scan kernel start and finish?  (probe flag 0x1000: s_memtime stamps into the checkpoints buffer)"""
 import json, os, sys, torch
 import numpy as np
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+PROBE_LIB = os.path.join(ROOT, "tools", "libzigma_scan_probes.so")      # the stamps are compiled only into a probe build
+if not os.path.exists(PROBE_LIB):               # (build it in the container before the GPU call)
+    from zigma_amd import build as zbuild
+    zbuild.build(verbose=False, lib=PROBE_LIB, extra_flags=("-DZIGMA_SCAN_PROBES",))
+os.environ["ZIGMA_AMD_LIB"] = PROBE_LIB
 from zigma_amd.selective_scan_interface import scan_raw
 dev, dt = "cuda", torch.bfloat16
 B, L, Di, N, R = 64, 1024, 1280, 16, 40

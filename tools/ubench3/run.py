@@ -1,0 +1,34 @@
+"""Build + run tools/ubench3/mfma_core.hip (see its header).  python tools/ubench3/run.py"""
+import ctypes, json, os, subprocess, sys
+HERE = os.path.dirname(os.path.abspath(__file__))
+src, lib = os.path.join(HERE, "mfma_core.hip"), os.path.join(HERE, "libubench3.so")
+if "--no-build" not in sys.argv and (not os.path.exists(lib) or os.path.getmtime(lib) < os.path.getmtime(src)):
+    subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=fast", "-shared", src, "-o", lib], check=True)
+import torch
+if not torch.cuda.is_available():
+    print("built", lib); sys.exit(0)
+L = ctypes.CDLL(lib)
+L.ubench3_launch.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+torch.manual_seed(0)
+inp = torch.rand(1024, device="cuda"); out = torch.zeros(1280 * 256, device="cuda")
+st = torch.cuda.current_stream().cuda_stream
+assert L.ubench3_launch(9, 1, 1, out.data_ptr(), inp.data_ptr(), st) == 0
+d = out[:256].cpu().view(64, 4)
+ok = all(float(d[l, i]) == float((4 * (l // 4) + i) * (100 + l)) for l in range(64) for i in range(4))
+print("4x4x1 layout D[reg i][lane 4b+j] = A[lane 4b+i] * B[lane 4b+j]:", ok)
+res = {}
+for mode in (0, 1, 2, 3, 4, 5, 6, 7, 8, 10, 11):
+    ts = []
+    for rep in range(5):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        assert L.ubench3_launch(mode, 1280, 64, out.data_ptr(), inp.data_ptr(), st) == 0
+        e1.record(); torch.cuda.synchronize()
+        ts.append(e0.elapsed_time(e1) * 1e3)
+    res[mode] = sorted(ts)[2]
+    if mode in (0, 1):
+        res[f"sum{mode}"] = float(out.double().sum())
+print(json.dumps(dict(what="scan core replica, 1280 WG x 64 tiles (B=64, Di=1280, L=1024), us", valu_core=res[0], mfma_core=res[1],
+                      mfma_core_no_y=res[2], valu_core_no_y=res[3], valu_y_in_registers=res[4], valu_y_b128_per_4_steps=res[5],
+                      c_from_scalar_loads=res[6], b_and_c_from_scalar_loads=res[7], b_and_c_from_16bit_scalar_loads=res[8], f32_scalar_loads_and_per_step_handover=res[10],
+                      b16_scalar_loads_and_per_step_handover=res[11], checksum_valu=res["sum0"], checksum_mfma=res["sum1"])))

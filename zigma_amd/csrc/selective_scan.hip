@@ -182,7 +182,12 @@ extern "C" int zigma_selective_scan_fwd(const zigma_scan_params_t *pp, void *str
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     if (p.batch < 0 || p.dim < 0 || p.seqlen < 0 || p.dstate < 1 || p.dstate > 256) return ZIGMA_ERR_SHAPE;  // MAX_DSTATE
     if (p.n_groups < 1 || p.dim % p.n_groups != 0) return ZIGMA_ERR_SHAPE;
-    if (p.flags & ~(ZIGMA_SCAN_Z_PREACTIVATED | ZIGMA_SCAN_PROBE_V1 | (1 << ZIGMA_SCAN_PROBE_PRIO_SHIFT) | 0x7000)) return ZIGMA_ERR_UNSUPPORTED;
+#ifdef ZIGMA_SCAN_PROBES
+    constexpr int kProbeBits = 0x7000;          // timing probes of scan_tok2.inc (probe library of tools/ only)
+#else
+    constexpr int kProbeBits = 0;
+#endif
+    if (p.flags & ~(ZIGMA_SCAN_Z_PREACTIVATED | ZIGMA_SCAN_PROBE_V1 | (1 << ZIGMA_SCAN_PROBE_PRIO_SHIFT) | kProbeBits)) return ZIGMA_ERR_UNSUPPORTED;
     if (p.batch == 0 || p.dim == 0 || p.seqlen == 0) return ZIGMA_OK;  // empty (pointers may be NULL): nothing to launch
     if (!p.u || !p.delta || !p.A || !p.B || !p.C) return ZIGMA_ERR_NULL;
     if (p.z && !p.out_z) return ZIGMA_ERR_NULL;
