@@ -16,7 +16,7 @@ def cross_attn_eligible(q, k, v, heads):
         return False
     if q.dim() != 3 or k.dim() != 3 or v.shape != k.shape or q.shape[2] != heads * 64 or k.shape[2] != heads * 64:
         return False
-    if k.shape[1] > 128 or k.shape[1] < 1 or q.shape[0] != k.shape[0]:
+    if k.shape[1] > 128 or k.shape[1] < 1 or q.shape[0] != k.shape[0] or q.shape[0] > 65535 or heads > 65535:      # (grid dims of the kernels)
         return False
     ok = lambda t: t.stride(2) == 1 and t.stride(1) % 8 == 0 and t.stride(0) % 8 == 0 and t.data_ptr() % 16 == 0
     return ok(q) and ok(k) and ok(v)
