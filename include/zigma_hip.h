@@ -27,12 +27,13 @@
 extern "C" {
 #endif
 
-#define ZIGMA_ABI_VERSION 6   /* 2: parameter blocks grew (row tables in the backward, checkpoints, reset_period)
+#define ZIGMA_ABI_VERSION 7   /* 2: parameter blocks grew (row tables in the backward, checkpoints, reset_period)
                                * 3: scan block: `info` out-field, ZIGMA_SCAN_Z_PREACTIVATED flag; zigma_linear_fwd
                                * 4: zigma_linear_params_t grew (gated residual epilogue); zigma_conv_x_proj_fwd, zigma_q_attn_fwd
                                * 5: pruned — zigma_q_attn_fwd and the dt product of zigma_conv_xproj_params_t removed (measured no faster,
                                *    archived under tools/experiments/)
-                               * 6: zigma_cross_attn_bwd / zigma_cross_attn_bwd_chunks added */
+                               * 6: zigma_cross_attn_bwd / zigma_cross_attn_bwd_chunks added
+                               * 7: reset_period in the two backward blocks (zigma_scan_bwd_params_t reuses its padding, zigma_conv_bwd_params_t grew) */
 
 /* zigma_scan_params_t.flags */
 #define ZIGMA_SCAN_Z_PREACTIVATED 2   /* z already holds silu(z) (the in_proj GEMM epilogue applied it): out_z = y * z */
@@ -243,7 +244,8 @@ typedef struct zigma_scan_bwd_params {
     int32_t delta_softplus;
     int32_t io_dtype;
     int32_t flags;           /* reserved, must be 0 */
-    int32_t pad_;
+    int32_t reset_period;    /* > 0 (multiple of 16): every batch row is a concatenation of independent sequences of that many steps,
+                              * as in zigma_scan_params_t: the state restarts there and no gradient crosses the boundary */
     int64_t u_batch_stride, u_l_stride;
     int64_t delta_batch_stride, delta_l_stride;
     int64_t z_batch_stride, z_l_stride;
@@ -309,6 +311,8 @@ typedef struct zigma_conv_bwd_params {
     const int32_t *x_row_index;
     void *workspace;
     int64_t workspace_bytes;
+    int32_t reset_period;   /* > 0 (multiple of 16): independent sequences of that many positions along seqlen (zigma_conv_params_t) */
+    int32_t pad_;
 } zigma_conv_bwd_params_t;
 
 int64_t zigma_causal_conv1d_bwd_workspace_bytes(const zigma_conv_bwd_params_t *p);

@@ -505,3 +505,100 @@ def test_cross_attn_bwd_kernel_vs_float64(Bsz, L, H, NC):
     # deterministic: fixed-order sums, no atomics
     dq2, dk2, dv2 = cross_attn_bwd(q, k, v, do, H)
     assert torch.equal(dq, dq2) and torch.equal(dk, dk2) and torch.equal(dv, dv2)
+
+
+@pytest.mark.parametrize("with_forward_checkpoints", [False, True])
+def test_scan_bwd_reset_period_vs_oracle_on_separate_sequences(with_forward_checkpoints):
+    """reset_period in the backward (the differentiable video temporal layers, reference mamba_simple.py:420-440 trained without the
+    transposing copies): a batch row that concatenates R-step sequences must give, step for step, the gradients the float64 oracle
+    (selective_scan_bwd_kernel.cuh:161-329 restated) gives for the same sequences as separate batch rows — with the checkpoints the
+    forward kernel wrote and with the backward's own first phase."""
+    from zigma_amd.selective_scan_interface import scan_bwd_tok, scan_raw
+    rng = np.random.default_rng(11)
+    Bsz, S, R, Dm, Nst = 3, 4, 16, 128, 16          # 3 rows of 4 sequences of 16 steps
+    L = S * R
+    mk = lambda *s: zo.bf16_round(rng.standard_normal(s).astype(np.float32))
+    c = dict(u=mk(Bsz, Dm, L), delta=zo.bf16_round((0.5 * rng.random((Bsz, Dm, L))).astype(np.float32)),
+             A=(-0.5 * rng.random((Dm, Nst)) - 0.05).astype(np.float32), B=mk(Bsz, Nst, L), C=mk(Bsz, Nst, L),
+             D=rng.standard_normal(Dm).astype(np.float32), z=mk(Bsz, Dm, L), delta_bias=(0.5 * rng.random(Dm)).astype(np.float32),
+             dout=mk(Bsz, Dm, L))
+    dt = torch.bfloat16
+    u, delta, z, dout, Bm, Cm = (tok(T(c[k], dt)) for k in ("u", "delta", "z", "dout", "B", "C"))
+    A, D, db = T(c["A"]), T(c["D"]), T(c["delta_bias"])
+    out, oz = torch.empty_like(u), torch.empty_like(u)
+    ck = torch.empty(Bsz, Dm // 64, L // 16, Nst, 64, device=DEV, dtype=torch.float32) if with_forward_checkpoints else None
+    info = []
+    scan_raw(u.transpose(1, 2), delta.transpose(1, 2), A, Bm.transpose(1, 2).unsqueeze(1), Cm.transpose(1, 2).unsqueeze(1), D,
+             z.transpose(1, 2), db, True, out=out.transpose(1, 2), out_z=oz.transpose(1, 2), checkpoints=ck, reset_period=R, info=info)
+    if with_forward_checkpoints:
+        assert info[1] == 1            # the forward kernel wrote them
+    du, ddelta, dA, dB, dC, dD, dz, dbias = scan_bwd_tok(u, delta, A, Bm, Cm, D, z, db, dout, out, True, checkpoints=ck, reset_period=R)
+    # the same sequences as separate rows: (B, D, S*R) -> (B*S, D, R)
+    sep = lambda a: a.reshape(a.shape[0], a.shape[1], S, R).transpose(0, 2, 1, 3).reshape(a.shape[0] * S, a.shape[1], R)
+    ref = zo.selective_scan_bwd(sep(c["u"]), sep(c["delta"]), c["A"], sep(c["B"]), sep(c["C"]), c["D"], sep(c["z"]), c["delta_bias"],
+                                sep(c["dout"]), True)
+    cat = lambda a: a.reshape(Bsz, S, a.shape[1], R).transpose(0, 2, 1, 3).reshape(Bsz, a.shape[1], L)
+    for got, key, tol in ((du.transpose(1, 2), "du", 1e-2), (ddelta.transpose(1, 2), "ddelta", 1e-2), (dz.transpose(1, 2), "dz", 1e-2),
+                          (dB.transpose(1, 2), "dB", 2e-3), (dC.transpose(1, 2), "dC", 2e-3)):
+        assert rel_err(N(got), cat(ref[key])) < tol, key
+    for got, key in ((dA, "dA"), (dD, "dD"), (dbias, "ddelta_bias")):
+        assert rel_err(N(got), ref[key]) < 2e-3, key
+
+
+def test_conv_bwd_reset_period_vs_oracle_on_separate_sequences():
+    """reset_period in the conv backward: the window (and the gradient) never crosses a sequence boundary; with a row table."""
+    from zigma_amd.causal_conv1d_interface import conv_bwd_tok
+    rng = np.random.default_rng(5)
+    Bsz, S, R, Dm = 2, 5, 16, 256
+    L = S * R
+    x = zo.bf16_round(rng.standard_normal((Bsz, L, Dm)).astype(np.float32))
+    dout = zo.bf16_round(rng.standard_normal((Bsz, L, Dm)).astype(np.float32))
+    w = zo.bf16_round((rng.standard_normal((Dm, 4)) * 0.5).astype(np.float32))
+    b = zo.bf16_round((rng.standard_normal(Dm) * 0.2).astype(np.float32))
+    perm = np.concatenate([s * R + rng.permutation(R) for s in range(S)]).astype(np.int32)       # reordering inside every sequence
+    dx, dw, db = conv_bwd_tok(T(x, torch.bfloat16), T(w, torch.bfloat16), T(b, torch.bfloat16), T(dout, torch.bfloat16), True,
+                              torch.from_numpy(perm).to(DEV), reset_period=R)
+    xs = x[:, perm].reshape(Bsz * S, R, Dm).transpose(0, 2, 1)
+    rdx, rdw, rdb = zo.causal_conv1d_bwd(xs, w, b, dout.reshape(Bsz * S, R, Dm).transpose(0, 2, 1), "silu")
+    ref_dx = np.empty_like(x)
+    ref_dx[:, perm] = rdx.transpose(0, 2, 1).reshape(Bsz, L, Dm)
+    assert rel_err(N(dx), ref_dx) < 5e-3
+    assert rel_err(N(dw), rdw) < 1e-4 and rel_err(N(db), rdb) < 1e-4
+
+
+def test_video_temporal_layers_train_without_transposing_copies():
+    """A video model (zzvideo_sst-like: spatial and temporal layers, 16 frames) trained through the strided-view form of its temporal
+    layers (reset_period in conv / scan forward AND backward, results and d(xz) as views) gives the same output and the same parameter /
+    input gradients as the transposing-copy form of the reference (mamba_simple.py:420-440), whose kernels the tests above pin; and the
+    strided form really ran (reset_period seen by the backward entry points)."""
+    from zigma_amd import _lib, mamba_simple
+    from zigma_amd.model_zigma import ZigMa
+    torch.manual_seed(0)
+    m = ZigMa(in_channels=4, embed_dim=128, depth=4, img_dim=8, patch_size=1, num_classes=5, scan_type="zzvideo_sst", video_frames=16,
+              use_pe=2, device=DEV, dtype=torch.bfloat16).train()
+    with torch.no_grad():
+        for blk in m.blocks:
+            blk.adaLN_modulation[-1].weight.normal_(std=0.05)
+            blk.adaLN_modulation[-1].bias.normal_(std=0.3)
+    x = torch.randn(2, 16, 4, 8, 8, device=DEV, dtype=torch.bfloat16)
+    t, y = torch.rand(2, device=DEV), torch.tensor([1, 3], device=DEV)
+    res = {}
+    for mode in (True, False):
+        mamba_simple.NO_COPY_TEMPORAL = mode
+        try:
+            m.zero_grad(set_to_none=True)
+            xin = x.clone().requires_grad_(True)
+            _lib.TRACE = []
+            out = m(xin, t, y)
+            (out.float() * torch.linspace(-1, 1, out.numel(), device=DEV).view(out.shape)).sum().backward()
+            trace, _lib.TRACE = _lib.TRACE, None
+        finally:
+            mamba_simple.NO_COPY_TEMPORAL = True
+        resets = [int(getattr(pb, "reset_period", 0)) for fn, _, pb in trace if fn in ("zigma_selective_scan_bwd", "zigma_causal_conv1d_bwd")]
+        res[mode] = (out.detach().float(), xin.grad.float(), {n: p.grad.float() for n, p in m.named_parameters() if p.grad is not None}, resets)
+    assert 16 in res[True][3] and not any(res[False][3])
+    assert rel_err(N(res[True][0]), N(res[False][0])) < 2e-3
+    assert rel_err(N(res[True][1]), N(res[False][1])) < 1e-2
+    assert res[True][2].keys() == res[False][2].keys()
+    worst = max((rel_err(N(res[True][2][n]), N(res[False][2][n])), n) for n in res[True][2] if float(res[False][2][n].abs().max()) > 0)
+    assert worst[0] < 2e-2, worst

@@ -72,7 +72,7 @@ class DtProjParams(C.Structure):
 
 
 class ScanBwdParams(C.Structure):
-    _fields_ = ([(n, i32) for n in ("batch", "dim", "seqlen", "dstate", "delta_softplus", "io_dtype", "flags", "pad_")]
+    _fields_ = ([(n, i32) for n in ("batch", "dim", "seqlen", "dstate", "delta_softplus", "io_dtype", "flags", "reset_period")]
                 + [(n, i64) for n in (
                     "u_batch_stride", "u_l_stride", "delta_batch_stride", "delta_l_stride", "z_batch_stride", "z_l_stride",
                     "out_batch_stride", "out_l_stride", "dout_batch_stride", "dout_l_stride", "du_batch_stride",
@@ -90,7 +90,7 @@ class ConvBwdParams(C.Structure):
                 + [(n, i64) for n in ("x_batch_stride", "x_l_stride", "dout_batch_stride", "dout_l_stride", "dx_batch_stride",
                                       "dx_l_stride", "weight_c_stride", "weight_width_stride")]
                 + [(n, vp) for n in ("x", "weight", "bias", "dout", "dx", "dweight", "dbias", "x_row_index", "workspace")]
-                + [("workspace_bytes", i64)])
+                + [("workspace_bytes", i64), ("reset_period", i32), ("pad_", i32)])
 
 
 class NormBwdParams(C.Structure):
@@ -179,7 +179,7 @@ def lib():
         L.zigma_strerror.restype = C.c_char_p
         L.zigma_abi_version.restype = C.c_int
         L.zigma_last_kernel.restype = C.c_char_p
-        if L.zigma_abi_version() != 6:
+        if L.zigma_abi_version() != 7:
             raise RuntimeError("zigma_amd: libzigma_hip.so ABI version mismatch")
         _lib = L
     return _lib

@@ -59,11 +59,11 @@ def causal_conv1d_fn(x, weight, bias=None, activation=None):
     return causal_conv1d_raw(x, weight, bias, activation in ["silu", "swish"])
 
 
-def conv_bwd_tok(x, weight, bias, dout, silu, x_row_index=None, dx=None):
+def conv_bwd_tok(x, weight, bias, dout, silu, x_row_index=None, dx=None, reset_period=0):
     """Backward of the token-major causal conv (zigma_causal_conv1d_bwd; reference causal_conv1d_cuda.causal_conv1d_bwd,
     causal_conv1d.cpp:191-283).  x, dout: (batch, seqlen, dim), channel stride 1; dout in SCAN order; x is read through
     x_row_index as in the forward and dx is scattered back through it.  Returns dx (dtype of x), dweight (dim, width) f32,
-    dbias (dim) f32 or None."""
+    dbias (dim) f32 or None.  reset_period > 0: independent sequences of that many positions along seqlen, as in the forward."""
     dev = _lib.require_device(x, weight, bias, dout, x_row_index)
     Bsz, L, Dm = x.shape
     if dout.shape != x.shape or x.stride(2) != 1 or dout.stride(2) != 1 or dout.dtype != x.dtype:
@@ -77,7 +77,7 @@ def conv_bwd_tok(x, weight, bias, dout, silu, x_row_index=None, dx=None):
         dw = db = None
         for a in range(0, Bsz, 65535):
             b = min(a + 65535, Bsz)
-            _, dwi, dbi = conv_bwd_tok(x[a:b], weight, bias, dout[a:b], silu, x_row_index, dx=dx[a:b])
+            _, dwi, dbi = conv_bwd_tok(x[a:b], weight, bias, dout[a:b], silu, x_row_index, dx=dx[a:b], reset_period=reset_period)
             dw = dwi if dw is None else dw + dwi
             db = dbi if db is None or dbi is None else db + dbi
         return dx, dw, db
@@ -92,6 +92,7 @@ def conv_bwd_tok(x, weight, bias, dout, silu, x_row_index=None, dx=None):
     P.weight_c_stride, P.weight_width_stride = w.stride(0), w.stride(1)
     P.x, P.weight, P.bias, P.dout, P.dx = _lib.ptr(x), _lib.ptr(w), _lib.ptr(bias), _lib.ptr(dout), _lib.ptr(dx)
     P.dweight, P.dbias = _lib.ptr(dw), _lib.ptr(db)
+    P.reset_period = int(reset_period)
     if bias is not None and bias.dtype != w.dtype:
         raise RuntimeError("bias must have the dtype of weight")
     if x_row_index is not None:

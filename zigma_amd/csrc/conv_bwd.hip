@@ -48,6 +48,10 @@ __global__ __launch_bounds__(64) void conv_bwd_tok_kernel(const zigma_conv_bwd_p
 
 #pragma unroll 1
     for (int k0 = k_seg; k0 < k_end; k0 += LT) {
+        // the sequence this tile belongs to (LT divides reset_period): positions outside [k_lo, k_hi) are another sequence — their x' reads
+        // as the zero padding, their dout does not reach this tile's dx
+        const int k_lo = p.reset_period > 0 ? (k0 / p.reset_period) * p.reset_period : 0;
+        const int k_hi = p.reset_period > 0 && k_lo + p.reset_period < L ? k_lo + p.reset_period : L;
         int rowv;      // lane i <- row of scan position k0 - (W-1) + i   (input gather AND dx scatter table)
         {
             int k = k0 - (W - 1) + lane;
@@ -60,13 +64,13 @@ __global__ __launch_bounds__(64) void conv_bwd_tok_kernel(const zigma_conv_bwd_p
             const int k = k0 - (W - 1) + i;
             const int row = __builtin_amdgcn_readlane(rowv, i);
             xr[i] = P{};
-            if (k >= 0 && k < L) xr[i] = buf_ld4<IO>(x_rs, lane_off, row * x_ls);
+            if (k >= k_lo && k < k_hi) xr[i] = buf_ld4<IO>(x_rs, lane_off, row * x_ls);
         }
 #pragma unroll
         for (int i = 0; i < ND; ++i) {
             const int k = k0 + i;
             gr[i] = P{};
-            if (k < L) gr[i] = buf_ld4<IO>(g_rs, lane_off, k * g_ls);     // dout is in scan order
+            if (k < k_hi) gr[i] = buf_ld4<IO>(g_rs, lane_off, k * g_ls);     // dout is in scan order
         }
         // dpre at positions k0 .. k0+LT+W-2
         float dp[ND][4];
@@ -176,6 +180,7 @@ extern "C" int zigma_causal_conv1d_bwd(const zigma_conv_bwd_params_t *pp, void *
     if (p.width < 2 || p.width > 4) return ZIGMA_ERR_SHAPE;
     if (p.batch < 0 || p.dim < 0 || p.seqlen < 0 || p.batch > 65535) return ZIGMA_ERR_SHAPE;
     if (p.flags != 0) return ZIGMA_ERR_UNSUPPORTED;
+    if (p.reset_period < 0 || p.reset_period % kCbLT != 0) return ZIGMA_ERR_SHAPE;
     if (p.batch == 0 || p.dim == 0 || p.seqlen == 0) return ZIGMA_OK;
     if (!p.x || !p.weight || !p.dout || !p.dx || !p.dweight) return ZIGMA_ERR_NULL;
     if (p.bias && !p.dbias) return ZIGMA_ERR_NULL;

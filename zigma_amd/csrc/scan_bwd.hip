@@ -114,6 +114,7 @@ __global__ __launch_bounds__(64 * NW, 2) void scan_bwd_kernel(const zigma_scan_b
     if (own_ck) fetch_fwd(0);
 #pragma unroll 1
     for (int t = 0; t < (own_ck ? n_tiles : 0); ++t) {
+        if (p.reset_period > 0 && (t * LT) % p.reset_period == 0) h[0] = h[1] = h[2] = h[3] = 0.f;      // start of an independent sequence
 #pragma unroll
         for (int i = 0; i < RPT; ++i) {
             const int row = wave * RPT + i, k = t * LT + row;
@@ -197,6 +198,8 @@ __global__ __launch_bounds__(64 * NW, 2) void scan_bwd_kernel(const zigma_scan_b
 
 #pragma unroll 1
     for (int t = n_tiles - 1; t >= 0; --t) {
+        // tile t + 1 started an independent sequence: nothing flows back from it
+        if (p.reset_period > 0 && ((t + 1) * LT) % p.reset_period == 0) adh[0] = adh[1] = adh[2] = adh[3] = 0.f;
         // ---- prologue: own rows (operands of this tile are in the prefetch registers) ----------------------------
         float dvr[RPT], ur[RPT], gr[RPT], sgr[RPT];
 #pragma unroll
@@ -417,6 +420,7 @@ extern "C" int zigma_selective_scan_bwd(const zigma_scan_bwd_params_t *pp, void 
     if (p.batch < 0 || p.dim < 0 || p.seqlen < 0) return ZIGMA_ERR_SHAPE;
     if (p.flags != 0) return ZIGMA_ERR_UNSUPPORTED;
     if (p.dim % 64 != 0 || (p.dstate != 16 && p.dstate != 8) || p.batch > 65535) return ZIGMA_ERR_SHAPE;
+    if (p.reset_period < 0 || p.reset_period % kBT != 0) return ZIGMA_ERR_SHAPE;
     if (p.batch == 0 || p.dim == 0 || p.seqlen == 0) return ZIGMA_OK;   // nothing to write (parameter gradients: caller zero-fills)
     if (!p.u || !p.delta || !p.A || !p.B || !p.C || !p.dout || !p.du || !p.ddelta || !p.dA || !p.dB || !p.dC) return ZIGMA_ERR_NULL;
     if (p.z && (!p.out || !p.dz)) return ZIGMA_ERR_NULL;

@@ -17,6 +17,8 @@ import torch.nn.functional as F
 from .linear import gated_residual_eligible, linear, linear_eligible
 from .selective_scan_interface import mamba_inner_tok
 
+NO_COPY_TEMPORAL = True      # video "t" layers on strided views (False: the transposing-copy form; A/B in the tests)
+
 
 def _int32_table(t, device):
     if t is None:
@@ -227,15 +229,23 @@ class Mamba(nn.Module):
             s_or_t = self.st_order[self.layer_idx]
             if s_or_t == "s":       # b (t k) c -> (b t) k c : a pure view
                 y = fwd(xz.view(batch * T, K, C2), self._perm).view(batch, seqlen, -1)
-            elif s_or_t == "t" and not torch.is_grad_enabled() and T % 16 == 0 and xz.numel() < 2 ** 29:
+            elif s_or_t == "t" and T % 16 == 0 and xz.numel() < 2 ** 29 and NO_COPY_TEMPORAL:
                 # b (t k) c -> scan over t for every (b, k) WITHOUT the two transposing copies: batch = k, sequence =
                 # (b, t) with stride K rows, conv window and SSM state restart every T steps (reset_period); the time
-                # tables are tiled over b.  Strided views in, strided view out.
+                # tables are tiled over b.  Strided views in, strided view out — in both directions: under autograd the
+                # backward kernels take the same views and d(xz) comes back as a view of a (b t, k, c) allocation.
                 perm_bt, out_bt = self._tiled_tables(batch, T)
-                y = torch.empty(batch, seqlen, C2 // 2, device=xz.device, dtype=xz.dtype)
-                mamba_inner_tok(xz.view(batch * T, K, C2).transpose(0, 1), self.conv1d.weight, self.conv1d.bias,
-                                self.x_proj.weight, self.dt_proj.weight, A, Dp, dtb, perm=perm_bt, out_rows=out_bt,
-                                delta_softplus=True, reset_period=T, out=y.view(batch * T, K, C2 // 2).transpose(0, 1))
+                xv = xz.view(batch * T, K, C2).transpose(0, 1)
+                if torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in (
+                        xz, self.conv1d.weight, self.conv1d.bias, self.x_proj.weight, self.dt_proj.weight, A, Dp, dtb)):
+                    y = mamba_inner_tok(xv, self.conv1d.weight, self.conv1d.bias, self.x_proj.weight, self.dt_proj.weight, A, Dp, dtb,
+                                        perm=perm_bt, out_rows=out_bt, delta_softplus=True, reset_period=T)
+                    y = y.transpose(0, 1).reshape(batch, seqlen, C2 // 2)        # (k, b t, c) view of a (b t, k, c) tensor: no copy
+                else:
+                    y = torch.empty(batch, seqlen, C2 // 2, device=xz.device, dtype=xz.dtype)
+                    mamba_inner_tok(xv, self.conv1d.weight, self.conv1d.bias,
+                                    self.x_proj.weight, self.dt_proj.weight, A, Dp, dtb, perm=perm_bt, out_rows=out_bt,
+                                    delta_softplus=True, reset_period=T, out=y.view(batch * T, K, C2 // 2).transpose(0, 1))
             elif s_or_t == "t":     # b (t k) c -> (b k) t c : one transposing copy in, one out
                 xt = xz.view(batch, T, K, C2).transpose(1, 2).reshape(batch * K, T, C2)
                 yt = fwd(xt, self._perm)

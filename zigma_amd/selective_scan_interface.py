@@ -274,7 +274,7 @@ BWD_MAX_BATCH = 65535        # batch limit of one zigma_selective_scan_bwd / zig
 
 
 def scan_bwd_tok(u, delta, A, B, C, D, z, delta_bias, dout, out, delta_softplus, *, dB=None, dC=None, dz=None,
-                 z_row_index=None, out_row_index=None, checkpoints=None):
+                 z_row_index=None, out_row_index=None, checkpoints=None, reset_period=0):
     """Backward of the token-major selective scan (zigma_selective_scan_bwd; reference selective_scan_cuda.bwd,
     selective_scan.cpp:338-492).
 
@@ -305,7 +305,7 @@ def scan_bwd_tok(u, delta, A, B, C, D, z, delta_bias, dout, out, delta_softplus,
             b = min(a + BWD_MAX_BATCH, Bsz)
             r = scan_bwd_tok(u[a:b], delta[a:b], A, B[a:b], C[a:b], D, sl(z, a, b), delta_bias, dout[a:b], sl(out, a, b), delta_softplus,
                              dB=dB[a:b], dC=dC[a:b], dz=sl(dz, a, b), z_row_index=z_row_index, out_row_index=out_row_index,
-                             checkpoints=None if checkpoints is None else checkpoints[a:b])
+                             checkpoints=None if checkpoints is None else checkpoints[a:b], reset_period=reset_period)
             du[a:b].copy_(r[0]); ddelta[a:b].copy_(r[1])
             dA = r[2] if dA is None else dA + r[2]
             dD = r[5] if dD is None or r[5] is None else dD + r[5]
@@ -334,6 +334,7 @@ def scan_bwd_tok(u, delta, A, B, C, D, z, delta_bias, dout, out, delta_softplus,
     P = _lib.ScanBwdParams()
     P.batch, P.dim, P.seqlen, P.dstate = Bsz, Dm, L, N
     P.delta_softplus, P.io_dtype, P.flags = int(bool(delta_softplus)), _lib.dtype_id(u), 0
+    P.reset_period = int(reset_period)       # > 0: independent sequences of that many steps along seqlen (as in the forward)
     for name, t in (("u", u), ("delta", delta), ("z", z), ("out", out), ("dout", dout), ("du", du), ("ddelta", ddelta),
                     ("dz", dz)):
         if t is not None:
@@ -374,21 +375,26 @@ class MambaInnerTokFn(torch.autograd.Function):
     through x_row_index).  Mirrors MambaInnerFn (selective_scan_interface.py:296-434) without its out_proj."""
 
     @staticmethod
-    def forward(ctx, xz, conv_w, conv_b, x_proj_w, dt_proj_w, A, D, delta_bias, perm, out_rows):
+    def forward(ctx, xz, conv_w, conv_b, x_proj_w, dt_proj_w, A, D, delta_bias, perm, out_rows, reset_period=0):
+        # reset_period > 0 (the video temporal layers): xz is the (k, b * t, 2 Di) strided VIEW of the (b * t, k, 2 Di) projection output —
+        # batch = pixel, sequence = the frames of every sample one after the other, conv window and state restart every t steps; the
+        # result and d(xz) are views of (b * t, k, .) allocations, so neither direction pays a transposing copy
         Bsz, L, C2 = xz.shape
         Di, R, N = C2 // 2, dt_proj_w.shape[1], A.shape[1]
         w = conv_w.reshape(Di, -1)
         x_half, z_half = xz[:, :, :Di], xz[:, :, Di:]
-        if USE_CONV_X_PROJ and conv_x_proj_eligible(x_half, w, conv_b, x_proj_w, perm):
+        if USE_CONV_X_PROJ and conv_x_proj_eligible(x_half, w, conv_b, x_proj_w, perm, reset_period):
             u, x_dbl = conv_x_proj(x_half, w, conv_b, x_proj_w, perm)      # one pass; the backward takes u and x_dbl as saved
         else:
             u = torch.empty(Bsz, L, Di, device=xz.device, dtype=xz.dtype)
-            causal_conv1d_raw(x_half.transpose(1, 2), w, conv_b, True, out=u.transpose(1, 2), x_row_index=perm)
+            causal_conv1d_raw(x_half.transpose(1, 2), w, conv_b, True, out=u.transpose(1, 2), x_row_index=perm, reset_period=reset_period)
             x_dbl = F.linear(u, x_proj_w)
         delta = F.linear(x_dbl[:, :, :R], dt_proj_w)
         Bm, Cm = x_dbl[:, :, R:R + N], x_dbl[:, :, R + N:R + 2 * N]
+        strided = not xz.is_contiguous()
         out = torch.empty(Bsz, L, Di, device=xz.device, dtype=xz.dtype)
-        y = torch.empty(Bsz, L, Di, device=xz.device, dtype=xz.dtype)
+        # (strided input = a transposed view: hand the result back as the same kind of view of an (L, Bsz, Di) allocation)
+        y = torch.empty(L, Bsz, Di, device=xz.device, dtype=xz.dtype).transpose(0, 1) if strided else torch.empty(Bsz, L, Di, device=xz.device, dtype=xz.dtype)
         # the states before every 16-step tile, for the backward's reverse sweep (the token-major kernel writes them on
         # its way: 4 * Di * N * L / 16 bytes per sample; anything else leaves the buffer alone and the backward recomputes)
         ck = None
@@ -398,11 +404,11 @@ class MambaInnerTokFn(torch.autograd.Function):
         scan_raw(u.transpose(1, 2), delta.transpose(1, 2), A, Bm.transpose(1, 2).unsqueeze(1),
                  Cm.transpose(1, 2).unsqueeze(1), D, z_half.transpose(1, 2), delta_bias, True,
                  out=out.transpose(1, 2), out_z=y.transpose(1, 2), z_row_index=perm, out_row_index=out_rows, checkpoints=ck,
-                 info=info)
+                 info=info, reset_period=reset_period)
         if ck is not None and info[1] != 1:          # the kernel that served the call does not write checkpoints
             ck = None
         ctx.save_for_backward(xz, conv_w, conv_b, x_proj_w, dt_proj_w, A, D, delta_bias, u, x_dbl, delta, out)
-        ctx.perm, ctx.out_rows, ctx.ck = perm, out_rows, ck
+        ctx.perm, ctx.out_rows, ctx.ck, ctx.reset_period = perm, out_rows, ck, reset_period
         return y
 
     @staticmethod
@@ -411,13 +417,15 @@ class MambaInnerTokFn(torch.autograd.Function):
         Bsz, L, C2 = xz.shape
         Di, R, N = C2 // 2, dt_proj_w.shape[1], A.shape[1]
         x_half, z_half = xz[:, :, :Di], xz[:, :, Di:]
-        dy = dy.contiguous()
-        dxz = torch.empty_like(xz)
+        if dy.stride(2) != 1:
+            dy = dy.contiguous()
+        rp = ctx.reset_period
+        dxz = torch.empty(L, Bsz, C2, device=xz.device, dtype=xz.dtype).transpose(0, 1) if not xz.is_contiguous() else torch.empty_like(xz)
         dx_dbl = torch.empty(Bsz, L, R + 2 * N, device=xz.device, dtype=torch.float32)
         du, ddelta, dA, _, _, dD, _, dbias = scan_bwd_tok(
             u, delta, A, x_dbl[:, :, R:R + N], x_dbl[:, :, R + N:R + 2 * N], D, z_half, delta_bias, dy, out, True,
             dB=dx_dbl[:, :, R:R + N], dC=dx_dbl[:, :, R + N:], dz=dxz[:, :, Di:], z_row_index=ctx.perm,
-            out_row_index=ctx.out_rows, checkpoints=ctx.ck)
+            out_row_index=ctx.out_rows, checkpoints=ctx.ck, reset_period=rp)
         ctx.ck = None
         dd2 = ddelta.reshape(-1, Di)
         dx_dbl[:, :, :R] = (dd2 @ dt_proj_w).reshape(Bsz, L, R)                  # d(x_dbl[:, :R]) = ddelta @ W_dt
@@ -425,19 +433,19 @@ class MambaInnerTokFn(torch.autograd.Function):
         dxd = dx_dbl.to(xz.dtype).reshape(-1, R + 2 * N)
         du = torch.addmm(du.reshape(-1, Di), dxd, x_proj_w).reshape(Bsz, L, Di)    # x_dbl = u @ W_x^T
         d_x_w = dxd.t() @ u.reshape(-1, Di)                                        # (R + 2N, Di)
-        _, d_cw, d_cb = conv_bwd_tok(x_half, conv_w, conv_b, du, True, ctx.perm, dx=dxz[:, :, :Di])
+        _, d_cw, d_cb = conv_bwd_tok(x_half, conv_w, conv_b, du, True, ctx.perm, dx=dxz[:, :, :Di], reset_period=rp)
         return (dxz, d_cw.to(conv_w.dtype).reshape(conv_w.shape), None if d_cb is None else d_cb.to(conv_b.dtype),
                 d_x_w.to(x_proj_w.dtype), d_dt_w.to(dt_proj_w.dtype), dA.to(A.dtype), dD.to(D.dtype),
-                None if dbias is None else dbias.to(delta_bias.dtype), None, None)
+                None if dbias is None else dbias.to(delta_bias.dtype), None, None, None)
 
 
 def mamba_inner_tok_train(xz, conv1d_weight, conv1d_bias, x_proj_weight, delta_proj_weight, A, D, delta_bias, *,
-                          perm=None, out_rows=None):
-    """Differentiable mamba_inner_tok (same row-table semantics)."""
+                          perm=None, out_rows=None, reset_period=0):
+    """Differentiable mamba_inner_tok (same row-table and reset_period semantics; a strided xz view gets a strided result view)."""
     if D is None or delta_bias is None:
         raise RuntimeError("the differentiable path expects D and delta_bias (ZigMa always has them)")
     return MambaInnerTokFn.apply(xz, conv1d_weight, conv1d_bias, x_proj_weight, delta_proj_weight, A, D, delta_bias, perm,
-                                 perm if out_rows is None else out_rows)
+                                 perm if out_rows is None else out_rows, int(reset_period))
 
 
 def selective_scan_cuda_fwd(u, delta, A, B, C, D_, z_, delta_bias_, delta_softplus):
@@ -504,17 +512,16 @@ def mamba_inner_tok(xz, conv1d_weight, conv1d_bias, x_proj_weight, delta_proj_we
           the inverse of perm; the caller passes out_rows = inverse(perm_rev) to reproduce exactly that.
     reset_period: > 0 = every batch row is a concatenation of independent sequences of that many steps (multiple of 16):
           conv window and SSM state restart there (the video temporal layers: batch = k, seqlen = b * t on strided views).
-          Forward only.
     Returns y (batch, seqlen, d_inner) in token order = out_z of the reference's scan, before out_proj.
     """
     if xz.dim() != 3 or xz.stride(2) != 1:
         raise RuntimeError("xz must be (batch, seqlen, 2*d_inner) with contiguous channels")
     if torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in (
             xz, conv1d_weight, conv1d_bias, x_proj_weight, delta_proj_weight, A, D, delta_bias)):
-        if B_proj_bias is not None or C_proj_bias is not None or not delta_softplus or out is not None or reset_period:
-            raise NotImplementedError("differentiable mamba_inner_tok: no B/C projection bias, softplus on, no out=, no reset_period")
+        if B_proj_bias is not None or C_proj_bias is not None or not delta_softplus or out is not None:
+            raise NotImplementedError("differentiable mamba_inner_tok: no B/C projection bias, softplus on, no out=")
         return mamba_inner_tok_train(xz, conv1d_weight, conv1d_bias, x_proj_weight, delta_proj_weight, A, D, delta_bias,
-                                     perm=perm, out_rows=out_rows)
+                                     perm=perm, out_rows=out_rows, reset_period=reset_period)
     Bsz, L, C2 = xz.shape
     Di = C2 // 2
     R = delta_proj_weight.shape[1]
