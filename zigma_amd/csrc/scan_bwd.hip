@@ -18,7 +18,9 @@
 //        the per-slab partials go to the workspace and are summed over the slabs by a finishing kernel
 //        (fixed order: bit-reproducible, unlike the reference's float atomics)
 //   epilogue (own rows): du = dt * sum_n dh B + g D,  ddelta = (u * sum_n dh B + sum_n A dh a h) * sigmoid(dt_raw)
-// B_l / C_l reach the FMAs as DPP row broadcasts of one register per 4-step group, exactly as in the forward.
+// B_l / C_l: the workgroup widens the tile's 16 x (N + N) values to fp32 once into LDS (one element of each per thread, fetched a tile
+// ahead); every wave reads its 4 states of a step with one wave-uniform ds_read_b128 per operand (a broadcast: no VALU slot, plain
+// operands) and the recurrences run two states per instruction (v_pk_mul_f32 / v_pk_fma_f32), as in scan_tok2_kernel.
 #include "scan_helpers.h"
 
 namespace zigma {
@@ -40,6 +42,7 @@ __global__ __launch_bounds__(64 * NW, 2) void scan_bwd_kernel(const zigma_scan_b
     __shared__ float s_dv[LT][64], s_u[LT][64], s_g[LT][64];
     __shared__ __attribute__((aligned(8))) float s_part[NW][LT][64][2];              // (sum_n dh B, sum_n A dh a h) per wave
     __shared__ __attribute__((aligned(16))) float s_red[NW][2][4 * kRedPitch];        // [wave][dB | dC][step in group][lane][state]
+    __shared__ __attribute__((aligned(16))) float s_bc[LT][2][16];                    // [step][B | C][state] of the tile, fp32
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -78,28 +81,22 @@ __global__ __launch_bounds__(64 * NW, 2) void scan_bwd_kernel(const zigma_scan_b
                                   Lm1 * B_ls + ((p.dstate - 1) * p.B_dstate_stride + 1) * ES);
     const rsrc_t C_rs = make_rsrc(reinterpret_cast<const io_t *>(p.C) + b * p.C_batch_stride,
                                   Lm1 * C_ls + ((p.dstate - 1) * p.C_dstate_stride + 1) * ES);
-    // B/C group register: lane -> (step s = (lane & 15) >> 2, state j = lane & 3), replicated in every 16-lane row
-    const int bc_s = (lane & 15) >> 2;
-    const unsigned B_lane = static_cast<unsigned>((n0 + (lane & 3)) * static_cast<int>(p.B_dstate_stride) * ES);
-    const unsigned C_lane = static_cast<unsigned>((n0 + (lane & 3)) * static_cast<int>(p.C_dstate_stride) * ES);
+    // B / C staging: thread -> (step, state) of the tile, one element of each (generic strides)
+    const int bc_step = static_cast<int>(threadIdx.x) / N, bc_n = static_cast<int>(threadIdx.x) % N;     // 64 NW threads = LT N values
+    const unsigned B_lane = static_cast<unsigned>(bc_n * static_cast<int>(p.B_dstate_stride) * ES);
+    const unsigned C_lane = static_cast<unsigned>(bc_n * static_cast<int>(p.C_dstate_stride) * ES);
     auto clampk = [&](int k) { return k < L ? k : L - 1; };
-    auto load_bc = [&](rsrc_t rs, unsigned lane_base, int ls, int t, int g) {   // steps beyond L: clamped (they carry dt = g = 0)
-        const int k = clampk(t * LT + g * 4 + bc_s);
-        return to_float<IO>(buf_ld<IO>(rs, lane_base + static_cast<unsigned>(k * ls), 0));
+    auto bc_raw = [&](rsrc_t rs, unsigned lane_base, int ls, int t) {      // steps beyond L: clamped (they carry dt = g = 0)
+        return buf_ld<IO>(rs, lane_base + static_cast<unsigned>(clampk(t * LT + bc_step) * ls), 0);
     };
     float *ck = (p.checkpoints ? const_cast<float *>(p.checkpoints) : ws.ck) + (static_cast<int64_t>(b) * n_slabs + slab) * n_tiles * N * 64;
 
-#define ZIGMA_BC(Bf, S, J) row_bcast<(S) * 4 + (J)>(Bf)
-
     // ================================ phase 1: forward, checkpoints ================================================
-    float h[4] = {0.f, 0.f, 0.f, 0.f};
+    v2f a2A = {a2[0], a2[1]}, a2B = {a2[2], a2[3]};
+    v2f hA = {0.f, 0.f}, hB = {0.f, 0.f};
     // operands are fetched ONE TILE AHEAD and kept raw (widened where consumed): a workgroup never waits for a load it
     // issued in the same tile (2 waves / SIMD cannot hide HBM latency by occupancy)
-    io_t pu[RPT], pd[RPT], pb[NG], pc[NG];
-    auto bc_raw = [&](rsrc_t rs, unsigned lane_base, int ls, int t, int g) {
-        const int k = clampk(t * LT + g * 4 + bc_s);
-        return buf_ld<IO>(rs, lane_base + static_cast<unsigned>(k * ls), 0);
-    };
+    io_t pu[RPT], pd[RPT], pb, pc;
     auto fetch_fwd = [&](int t) {
 #pragma unroll
         for (int i = 0; i < RPT; ++i) {
@@ -107,14 +104,13 @@ __global__ __launch_bounds__(64 * NW, 2) void scan_bwd_kernel(const zigma_scan_b
             pu[i] = buf_ld<IO>(u_rs, lane_off, kk * u_ls);
             pd[i] = buf_ld<IO>(d_rs, lane_off, kk * d_ls);
         }
-#pragma unroll
-        for (int g = 0; g < NG; ++g) pb[g] = bc_raw(B_rs, B_lane, B_ls, t, g);
+        pb = bc_raw(B_rs, B_lane, B_ls, t);
     };
     const bool own_ck = p.checkpoints == nullptr;      // else: the forward kernel already wrote them
     if (own_ck) fetch_fwd(0);
 #pragma unroll 1
     for (int t = 0; t < (own_ck ? n_tiles : 0); ++t) {
-        if (p.reset_period > 0 && (t * LT) % p.reset_period == 0) h[0] = h[1] = h[2] = h[3] = 0.f;      // start of an independent sequence
+        if (p.reset_period > 0 && (t * LT) % p.reset_period == 0) hA = hB = v2f{0.f, 0.f};      // start of an independent sequence
 #pragma unroll
         for (int i = 0; i < RPT; ++i) {
             const int row = wave * RPT + i, k = t * LT + row;
@@ -125,33 +121,29 @@ __global__ __launch_bounds__(64 * NW, 2) void scan_bwd_kernel(const zigma_scan_b
             s_dv[row][lane] = dv;
             s_u[row][lane] = k < L ? uf : 0.f;
         }
-        float Bf[NG];
-#pragma unroll
-        for (int g = 0; g < NG; ++g) Bf[g] = to_float<IO>(pb[g]);
+        s_bc[bc_step][0][bc_n] = to_float<IO>(pb);
         if (t + 1 < n_tiles) fetch_fwd(t + 1);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) ck[(static_cast<int64_t>(t) * N + n0 + j) * 64 + lane] = h[j];
+        ck[(static_cast<int64_t>(t) * N + n0 + 0) * 64 + lane] = hA.x;
+        ck[(static_cast<int64_t>(t) * N + n0 + 1) * 64 + lane] = hA.y;
+        ck[(static_cast<int64_t>(t) * N + n0 + 2) * 64 + lane] = hB.x;
+        ck[(static_cast<int64_t>(t) * N + n0 + 3) * 64 + lane] = hB.y;
         __syncthreads();
 #pragma unroll
-        for (int g = 0; g < NG; ++g) {
-#pragma unroll
-            for (int si = 0; si < 4; ++si) {
-                const int s = g * 4 + si;
-                const float dv = s_dv[s][lane], du = dv * s_u[s][lane];
-                float bb[4];
-                if (si == 0) { bb[0] = ZIGMA_BC(Bf[g], 0, 0); bb[1] = ZIGMA_BC(Bf[g], 0, 1); bb[2] = ZIGMA_BC(Bf[g], 0, 2); bb[3] = ZIGMA_BC(Bf[g], 0, 3); }
-                if (si == 1) { bb[0] = ZIGMA_BC(Bf[g], 1, 0); bb[1] = ZIGMA_BC(Bf[g], 1, 1); bb[2] = ZIGMA_BC(Bf[g], 1, 2); bb[3] = ZIGMA_BC(Bf[g], 1, 3); }
-                if (si == 2) { bb[0] = ZIGMA_BC(Bf[g], 2, 0); bb[1] = ZIGMA_BC(Bf[g], 2, 1); bb[2] = ZIGMA_BC(Bf[g], 2, 2); bb[3] = ZIGMA_BC(Bf[g], 2, 3); }
-                if (si == 3) { bb[0] = ZIGMA_BC(Bf[g], 3, 0); bb[1] = ZIGMA_BC(Bf[g], 3, 1); bb[2] = ZIGMA_BC(Bf[g], 3, 2); bb[3] = ZIGMA_BC(Bf[g], 3, 3); }
-#pragma unroll
-                for (int j = 0; j < 4; ++j) h[j] = __builtin_fmaf(fast_exp2(dv * a2[j]), h[j], bb[j] * du);
-            }
+        for (int s = 0; s < LT; ++s) {
+            const float dv = s_dv[s][lane], du = dv * s_u[s][lane];
+            const v4f Bv = *reinterpret_cast<const v4f *>(&s_bc[s][0][n0]);
+            const v2f dtv = {dv, dv}, duv = {du, du};
+            const v2f xA = a2A * dtv, xB = a2B * dtv;
+            const v2f eA = {fast_exp2(xA.x), fast_exp2(xA.y)}, eB = {fast_exp2(xB.x), fast_exp2(xB.y)};
+            hA = __builtin_elementwise_fma(eA, hA, v2f{Bv.x, Bv.y} * duv);
+            hB = __builtin_elementwise_fma(eB, hB, v2f{Bv.z, Bv.w} * duv);
         }
         __syncthreads();
     }
 
     // ================================ phase 2: reverse sweep =========================================================
-    float adh[4] = {0.f, 0.f, 0.f, 0.f}, dA[4] = {0.f, 0.f, 0.f, 0.f};
+    v2f adhA = {0.f, 0.f}, adhB = {0.f, 0.f}, dAA = {0.f, 0.f}, dAB = {0.f, 0.f};
+    const v2f AnA = {An[0], An[1]}, AnB = {An[2], An[3]};
     float dD_acc = 0.f, db_acc = 0.f;
     float *bc_out = ws.bc + (static_cast<int64_t>(b) * n_slabs + slab) * n_tiles * LT * 2 * N;
     float *red_b = &s_red[wave][0][0], *red_c = &s_red[wave][1][0];
@@ -184,11 +176,8 @@ __global__ __launch_bounds__(64 * NW, 2) void scan_bwd_kernel(const zigma_scan_b
                 po[i] = buf_ld<IO>(o_rs, lane_off, orow * o_ls);
             }
         }
-#pragma unroll
-        for (int g = 0; g < NG; ++g) {
-            pb[g] = bc_raw(B_rs, B_lane, B_ls, t, g);
-            pc[g] = bc_raw(C_rs, C_lane, C_ls, t, g);
-        }
+        pb = bc_raw(B_rs, B_lane, B_ls, t);
+        pc = bc_raw(C_rs, C_lane, C_ls, t);
 #pragma unroll
         for (int j = 0; j < 4; ++j) h0n[j] = ck[(static_cast<int64_t>(t) * N + n0 + j) * 64 + lane];
     };
@@ -199,7 +188,7 @@ __global__ __launch_bounds__(64 * NW, 2) void scan_bwd_kernel(const zigma_scan_b
 #pragma unroll 1
     for (int t = n_tiles - 1; t >= 0; --t) {
         // tile t + 1 started an independent sequence: nothing flows back from it
-        if (p.reset_period > 0 && ((t + 1) * LT) % p.reset_period == 0) adh[0] = adh[1] = adh[2] = adh[3] = 0.f;
+        if (p.reset_period > 0 && ((t + 1) * LT) % p.reset_period == 0) adhA = adhB = v2f{0.f, 0.f};
         // ---- prologue: own rows (operands of this tile are in the prefetch registers) ----------------------------
         float dvr[RPT], ur[RPT], gr[RPT], sgr[RPT];
 #pragma unroll
@@ -229,14 +218,9 @@ __global__ __launch_bounds__(64 * NW, 2) void scan_bwd_kernel(const zigma_scan_b
             s_u[row][lane] = ur[i];
             s_g[row][lane] = gr[i];
         }
-        float Bf[NG], Cf[NG], h0[4];
-#pragma unroll
-        for (int g = 0; g < NG; ++g) {
-            Bf[g] = to_float<IO>(pb[g]);
-            Cf[g] = to_float<IO>(pc[g]);
-        }
-#pragma unroll
-        for (int j = 0; j < 4; ++j) h0[j] = h0n[j];
+        s_bc[bc_step][0][bc_n] = to_float<IO>(pb);
+        s_bc[bc_step][1][bc_n] = to_float<IO>(pc);
+        const v2f h0A = {h0n[0], h0n[1]}, h0B = {h0n[2], h0n[3]};
         if (t > 0) {
             fetch_bwd(t - 1);
             if (t > 1) load_tabs(t - 2);
@@ -244,29 +228,23 @@ __global__ __launch_bounds__(64 * NW, 2) void scan_bwd_kernel(const zigma_scan_b
         __syncthreads();
 
         // ---- forward recompute of the 16 states -----------------------------------------------------------------
-        float hs[LT][4];
+        v2f hsA[LT], hsB[LT];
         {
-            float hh[4] = {h0[0], h0[1], h0[2], h0[3]};
+            v2f hhA = h0A, hhB = h0B;
 #pragma unroll
-            for (int g = 0; g < NG; ++g) {
-#pragma unroll
-                for (int si = 0; si < 4; ++si) {
-                    const int s = g * 4 + si;
-                    const float dv = s_dv[s][lane], du = dv * s_u[s][lane];
-                    float bb[4];
-                    if (si == 0) { bb[0] = ZIGMA_BC(Bf[g], 0, 0); bb[1] = ZIGMA_BC(Bf[g], 0, 1); bb[2] = ZIGMA_BC(Bf[g], 0, 2); bb[3] = ZIGMA_BC(Bf[g], 0, 3); }
-                    if (si == 1) { bb[0] = ZIGMA_BC(Bf[g], 1, 0); bb[1] = ZIGMA_BC(Bf[g], 1, 1); bb[2] = ZIGMA_BC(Bf[g], 1, 2); bb[3] = ZIGMA_BC(Bf[g], 1, 3); }
-                    if (si == 2) { bb[0] = ZIGMA_BC(Bf[g], 2, 0); bb[1] = ZIGMA_BC(Bf[g], 2, 1); bb[2] = ZIGMA_BC(Bf[g], 2, 2); bb[3] = ZIGMA_BC(Bf[g], 2, 3); }
-                    if (si == 3) { bb[0] = ZIGMA_BC(Bf[g], 3, 0); bb[1] = ZIGMA_BC(Bf[g], 3, 1); bb[2] = ZIGMA_BC(Bf[g], 3, 2); bb[3] = ZIGMA_BC(Bf[g], 3, 3); }
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        hh[j] = __builtin_fmaf(fast_exp2(dv * a2[j]), hh[j], bb[j] * du);
-                        hs[s][j] = hh[j];
-                    }
-                }
+            for (int s = 0; s < LT; ++s) {
+                const float dv = s_dv[s][lane], du = dv * s_u[s][lane];
+                const v4f Bv = *reinterpret_cast<const v4f *>(&s_bc[s][0][n0]);
+                const v2f dtv = {dv, dv}, duv = {du, du};
+                const v2f xA = a2A * dtv, xB = a2B * dtv;
+                const v2f eA = {fast_exp2(xA.x), fast_exp2(xA.y)}, eB = {fast_exp2(xB.x), fast_exp2(xB.y)};
+                hhA = __builtin_elementwise_fma(eA, hhA, v2f{Bv.x, Bv.y} * duv);
+                hhB = __builtin_elementwise_fma(eB, hhB, v2f{Bv.z, Bv.w} * duv);
+                hsA[s] = hhA;
+                hsB[s] = hhB;
             }
         }
-        // ---- reverse recurrence + gradients ------------------------------------------------------------------------
+        // ---- reverse recurrence + gradients (two states per instruction) ----------------------------------------------
 #pragma unroll
         for (int g = NG - 1; g >= 0; --g) {
 #pragma unroll
@@ -274,33 +252,23 @@ __global__ __launch_bounds__(64 * NW, 2) void scan_bwd_kernel(const zigma_scan_b
                 const int s = g * 4 + si;
                 const float dv = s_dv[s][lane], uu = s_u[s][lane], gg = s_g[s][lane];
                 const float du = dv * uu;
-                float bb[4], cc[4];
-                if (si == 0) { bb[0] = ZIGMA_BC(Bf[g], 0, 0); bb[1] = ZIGMA_BC(Bf[g], 0, 1); bb[2] = ZIGMA_BC(Bf[g], 0, 2); bb[3] = ZIGMA_BC(Bf[g], 0, 3);
-                               cc[0] = ZIGMA_BC(Cf[g], 0, 0); cc[1] = ZIGMA_BC(Cf[g], 0, 1); cc[2] = ZIGMA_BC(Cf[g], 0, 2); cc[3] = ZIGMA_BC(Cf[g], 0, 3); }
-                if (si == 1) { bb[0] = ZIGMA_BC(Bf[g], 1, 0); bb[1] = ZIGMA_BC(Bf[g], 1, 1); bb[2] = ZIGMA_BC(Bf[g], 1, 2); bb[3] = ZIGMA_BC(Bf[g], 1, 3);
-                               cc[0] = ZIGMA_BC(Cf[g], 1, 0); cc[1] = ZIGMA_BC(Cf[g], 1, 1); cc[2] = ZIGMA_BC(Cf[g], 1, 2); cc[3] = ZIGMA_BC(Cf[g], 1, 3); }
-                if (si == 2) { bb[0] = ZIGMA_BC(Bf[g], 2, 0); bb[1] = ZIGMA_BC(Bf[g], 2, 1); bb[2] = ZIGMA_BC(Bf[g], 2, 2); bb[3] = ZIGMA_BC(Bf[g], 2, 3);
-                               cc[0] = ZIGMA_BC(Cf[g], 2, 0); cc[1] = ZIGMA_BC(Cf[g], 2, 1); cc[2] = ZIGMA_BC(Cf[g], 2, 2); cc[3] = ZIGMA_BC(Cf[g], 2, 3); }
-                if (si == 3) { bb[0] = ZIGMA_BC(Bf[g], 3, 0); bb[1] = ZIGMA_BC(Bf[g], 3, 1); bb[2] = ZIGMA_BC(Bf[g], 3, 2); bb[3] = ZIGMA_BC(Bf[g], 3, 3);
-                               cc[0] = ZIGMA_BC(Cf[g], 3, 0); cc[1] = ZIGMA_BC(Cf[g], 3, 1); cc[2] = ZIGMA_BC(Cf[g], 3, 2); cc[3] = ZIGMA_BC(Cf[g], 3, 3); }
-                float sp = 0.f, sA = 0.f;
-                v4f pB, pC;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const float e = fast_exp2(dv * a2[j]);
-                    const float dh = __builtin_fmaf(cc[j], gg, adh[j]);
-                    const float hm = s > 0 ? hs[s > 0 ? s - 1 : 0][j] : h0[j];
-                    const float t2 = dh * (e * hm);                 // dh * a_l * h_{l-1}
-                    dA[j] = __builtin_fmaf(dv, t2, dA[j]);
-                    sA = __builtin_fmaf(An[j], t2, sA);
-                    sp = __builtin_fmaf(dh, bb[j], sp);
-                    adh[j] = e * dh;
-                    pB[j] = dh * du;
-                    pC[j] = gg * hs[s][j];
-                }
-                *reinterpret_cast<v2f *>(&s_part[wave][s][lane][0]) = v2f{sp, sA};
-                *reinterpret_cast<v4f *>(red_b + si * kRedPitch + lane * 4) = pB;
-                *reinterpret_cast<v4f *>(red_c + si * kRedPitch + lane * 4) = pC;
+                const v4f Bv = *reinterpret_cast<const v4f *>(&s_bc[s][0][n0]), Cv = *reinterpret_cast<const v4f *>(&s_bc[s][1][n0]);
+                const v2f dtv = {dv, dv}, duv = {du, du}, ggv = {gg, gg};
+                const v2f xA = a2A * dtv, xB = a2B * dtv;
+                const v2f eA = {fast_exp2(xA.x), fast_exp2(xA.y)}, eB = {fast_exp2(xB.x), fast_exp2(xB.y)};
+                const v2f dhA = __builtin_elementwise_fma(v2f{Cv.x, Cv.y}, ggv, adhA), dhB = __builtin_elementwise_fma(v2f{Cv.z, Cv.w}, ggv, adhB);
+                const v2f hmA = s > 0 ? hsA[s > 0 ? s - 1 : 0] : h0A, hmB = s > 0 ? hsB[s > 0 ? s - 1 : 0] : h0B;
+                const v2f t2A = dhA * (eA * hmA), t2B = dhB * (eB * hmB);         // dh * a_l * h_{l-1}
+                dAA = __builtin_elementwise_fma(dtv, t2A, dAA);
+                dAB = __builtin_elementwise_fma(dtv, t2B, dAB);
+                const v2f sA2 = __builtin_elementwise_fma(AnB, t2B, AnA * t2A);
+                const v2f sp2 = __builtin_elementwise_fma(dhB, v2f{Bv.z, Bv.w}, dhA * v2f{Bv.x, Bv.y});
+                adhA = eA * dhA;
+                adhB = eB * dhB;
+                const v2f pBA = dhA * duv, pBB = dhB * duv, pCA = ggv * hsA[s], pCB = ggv * hsB[s];
+                *reinterpret_cast<v2f *>(&s_part[wave][s][lane][0]) = v2f{sp2.x + sp2.y, sA2.x + sA2.y};
+                *reinterpret_cast<v4f *>(red_b + si * kRedPitch + lane * 4) = v4f{pBA.x, pBA.y, pBB.x, pBB.y};
+                *reinterpret_cast<v4f *>(red_c + si * kRedPitch + lane * 4) = v4f{pCA.x, pCA.y, pCB.x, pCB.y};
             }
             // cross-channel sums of the group: lane -> (half wave, dB | dC, step, state); 32 values each, then fold the halves
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -344,11 +312,12 @@ __global__ __launch_bounds__(64 * NW, 2) void scan_bwd_kernel(const zigma_scan_b
         // s_dv/s_u/s_g/s_part are rewritten only after the next tile's first barrier -> no third barrier needed:
         // the prologue of tile t-1 writes s_dv..s_g, which the core of tile t no longer reads (barrier above).
     }
-#undef ZIGMA_BC
     // ---- per-sample parameter gradients -> workspace (summed over the batch by the finishing kernel) -------------------
     float *pa = ws.pa + (static_cast<int64_t>(b) * p.dim + c) * (N + 2);
-#pragma unroll
-    for (int j = 0; j < 4; ++j) pa[n0 + j] = dA[j];
+    pa[n0 + 0] = dAA.x;
+    pa[n0 + 1] = dAA.y;
+    pa[n0 + 2] = dAB.x;
+    pa[n0 + 3] = dAB.y;
     __syncthreads();
     s_part[wave][0][lane][0] = dD_acc;
     s_part[wave][0][lane][1] = db_acc;
