@@ -27,13 +27,14 @@
 extern "C" {
 #endif
 
-#define ZIGMA_ABI_VERSION 7   /* 2: parameter blocks grew (row tables in the backward, checkpoints, reset_period)
+#define ZIGMA_ABI_VERSION 8   /* 2: parameter blocks grew (row tables in the backward, checkpoints, reset_period)
                                * 3: scan block: `info` out-field, ZIGMA_SCAN_Z_PREACTIVATED flag; zigma_linear_fwd
                                * 4: zigma_linear_params_t grew (gated residual epilogue); zigma_conv_x_proj_fwd, zigma_q_attn_fwd
                                * 5: pruned — zigma_q_attn_fwd and the dt product of zigma_conv_xproj_params_t removed (measured no faster,
                                *    archived under tools/experiments/)
                                * 6: zigma_cross_attn_bwd / zigma_cross_attn_bwd_chunks added
-                               * 7: reset_period in the two backward blocks (zigma_scan_bwd_params_t reuses its padding, zigma_conv_bwd_params_t grew) */
+                               * 7: reset_period in the two backward blocks (zigma_scan_bwd_params_t reuses its padding, zigma_conv_bwd_params_t grew)
+                               * 8: zigma_patch_embed_fwd, zigma_timestep_embed_fwd, zigma_final_layer_fwd, zigma_skinny_linear_fwd added */
 
 /* zigma_scan_params_t.flags */
 #define ZIGMA_SCAN_Z_PREACTIVATED 2   /* z already holds silu(z) (the in_proj GEMM epilogue applied it): out_z = y * z */
@@ -497,6 +498,68 @@ typedef struct zigma_linear_params {
 } zigma_linear_params_t;
 
 int zigma_linear_fwd(const zigma_linear_params_t *p, void *stream);
+
+/* ------------------------------------------------------------------------------------------
+ * The small per-forward operators around the blocks (bf16 models; each replaces a chain of library GEMM + ATen elementwise launches):
+ *
+ * zigma_patch_embed_fwd: PatchEmbed (a conv with kernel == stride; timm, call site model_zigma.py:608-614,924) + bias, and the
+ *   position table of model_zigma.py:939-940:  out[b, l, :] = bf16(bf16(W x_patch(b, l) + bias) + pos[l, :]).
+ *   x (batch, in_chans, height, width) with element strides (w stride 1); weight (embed_dim, in_chans * patch * patch) contiguous;
+ *   bias (embed_dim) or NULL; pos (L, embed_dim) rows of pitch pos_row_stride or NULL; out (batch, L, embed_dim), L = (h / p)(w / p).
+ *   Limits: embed_dim % 8 == 0, in_chans * patch^2 * embed_dim * 4 <= 64 KB, out / pos / bias 16-byte aligned.
+ * zigma_timestep_embed_fwd: TimestepEmbedder.timestep_embedding (model_zigma.py:247-268): out[b] = [cos(t_b f), sin(t_b f)] with t and the
+ *   dim / 2 frequencies f in the model dtype, product and functions in fp32.
+ * zigma_final_layer_fwd: FinalLayer without conditioning (model_zigma.py:313-337): out = Linear(LayerNorm(x, no affine, eps)), n_out <= 16,
+ *   cols % 8 == 0, cols <= 2048; x rows 16-byte aligned; out (rows, n_out) rows of pitch out_row_stride.
+ * zigma_skinny_linear_fwd: out = act(x) W^T + bias for m <= 64 rows (the timestep MLP :232-275 and the adaLN modulation :441, :447 of all
+ *   blocks in one call); flags bit 0: act = SiLU (rounded to bf16 like the reference's module), else identity.
+ *   Limits: n % 16 == 0, k % 128 == 0, k <= 1024; x, w rows 16-byte aligned, out rows 8-byte aligned, bias 8-byte aligned.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct zigma_patch_embed_params {
+    int32_t batch, in_chans, height, width, patch, embed_dim;
+    int32_t dtype;   /* ZIGMA_BF16 */
+    int32_t flags;   /* reserved, must be 0 */
+    int64_t x_batch_stride, x_chan_stride, x_row_stride;
+    int64_t pos_row_stride, out_batch_stride, out_row_stride;
+    const void *x, *weight, *bias, *pos;
+    void *out;
+} zigma_patch_embed_params_t;
+
+typedef struct zigma_timestep_embed_params {
+    int32_t batch, dim;
+    int32_t dtype;   /* ZIGMA_BF16 */
+    int32_t flags;   /* reserved, must be 0 */
+    int64_t out_row_stride;
+    const void *t, *freqs;
+    void *out;
+} zigma_timestep_embed_params_t;
+
+typedef struct zigma_final_layer_params {
+    int64_t rows;
+    int32_t cols, n_out;
+    int32_t dtype;   /* ZIGMA_BF16 */
+    int32_t flags;   /* reserved, must be 0 */
+    float eps;
+    int32_t pad_;
+    int64_t x_row_stride, out_row_stride;
+    const void *x, *weight, *bias;
+    void *out;
+} zigma_final_layer_params_t;
+
+typedef struct zigma_skinny_params {
+    int32_t m, n, k;
+    int32_t dtype;   /* ZIGMA_BF16 */
+    int32_t flags;   /* bit 0: SiLU on x */
+    int32_t pad_;
+    int64_t x_row_stride, w_row_stride, out_row_stride;
+    const void *x, *w, *bias;
+    void *out;
+} zigma_skinny_params_t;
+
+int zigma_patch_embed_fwd(const zigma_patch_embed_params_t *p, void *stream);
+int zigma_timestep_embed_fwd(const zigma_timestep_embed_params_t *p, void *stream);
+int zigma_final_layer_fwd(const zigma_final_layer_params_t *p, void *stream);
+int zigma_skinny_linear_fwd(const zigma_skinny_params_t *p, void *stream);
 
 /* ------------------------------------------------------------------------------------------ */
 const char *zigma_strerror(int status);

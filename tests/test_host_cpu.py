@@ -33,7 +33,7 @@ def test_cabi_exports_every_declared_symbol(libpath):
         assert hasattr(L, name), name
     L.zigma_abi_version.restype = ctypes.c_int
     L.zigma_strerror.restype = ctypes.c_char_p
-    assert L.zigma_abi_version() == 7
+    assert L.zigma_abi_version() == 8
     assert L.zigma_strerror(-2) == b"size out of the supported range"
     from zigma_amd import _lib
     assert set(_lib.EXPORTS) <= declared
@@ -47,7 +47,9 @@ def test_ctypes_structs_match_the_header():
                "zigma_scan_bwd_params_t": _lib.ScanBwdParams, "zigma_conv_bwd_params_t": _lib.ConvBwdParams,
                "zigma_norm_bwd_params_t": _lib.NormBwdParams, "zigma_xattn_params_t": _lib.XAttnParams, "zigma_xproj_params_t": _lib.XProjParams,
                "zigma_linear_params_t": _lib.LinearParams, "zigma_conv_xproj_params_t": _lib.ConvXProjParams,
-               "zigma_glue_bwd_params_t": _lib.GlueBwdParams, "zigma_xattn_bwd_params_t": _lib.XAttnBwdParams}
+               "zigma_glue_bwd_params_t": _lib.GlueBwdParams, "zigma_xattn_bwd_params_t": _lib.XAttnBwdParams, "zigma_patch_embed_params_t": _lib.PatchEmbedParams,
+               "zigma_timestep_embed_params_t": _lib.TimestepEmbedParams, "zigma_final_layer_params_t": _lib.FinalLayerParams,
+               "zigma_skinny_params_t": _lib.SkinnyParams}
     lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "zigma_hip.h"', "int main(void){"]
     for cname, st in structs.items():
         lines.append(f'printf("{cname} %zu\\n", sizeof({cname}));')

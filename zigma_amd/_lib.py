@@ -118,6 +118,26 @@ class XAttnBwdParams(C.Structure):
                 + [(n, vp) for n in ("q", "k", "v", "dout", "dq", "dk_part", "dv_part")])
 
 
+class PatchEmbedParams(C.Structure):
+    _fields_ = ([(n, i32) for n in ("batch", "in_chans", "height", "width", "patch", "embed_dim", "dtype", "flags")]
+                + [(n, i64) for n in ("x_batch_stride", "x_chan_stride", "x_row_stride", "pos_row_stride", "out_batch_stride", "out_row_stride")]
+                + [(n, vp) for n in ("x", "weight", "bias", "pos", "out")])
+
+
+class TimestepEmbedParams(C.Structure):
+    _fields_ = [("batch", i32), ("dim", i32), ("dtype", i32), ("flags", i32), ("out_row_stride", i64), ("t", vp), ("freqs", vp), ("out", vp)]
+
+
+class FinalLayerParams(C.Structure):
+    _fields_ = ([("rows", i64), ("cols", i32), ("n_out", i32), ("dtype", i32), ("flags", i32), ("eps", f32), ("pad_", i32),
+                 ("x_row_stride", i64), ("out_row_stride", i64)] + [(n, vp) for n in ("x", "weight", "bias", "out")])
+
+
+class SkinnyParams(C.Structure):
+    _fields_ = ([(n, i32) for n in ("m", "n", "k", "dtype", "flags", "pad_")] + [(n, i64) for n in ("x_row_stride", "w_row_stride", "out_row_stride")]
+                + [(n, vp) for n in ("x", "w", "bias", "out")])
+
+
 class GlueBwdParams(C.Structure):
     _fields_ = ([("rows", i64), ("cols", i32), ("rows_per_batch", i32), ("dtype", i32), ("flags", i32), ("s_add", f32), ("pad_", i32)]
                 + [(n, i64) for n in ("dy_row_stride", "a_row_stride", "out_row_stride", "s_batch_stride")]
@@ -145,7 +165,8 @@ EXPORTS = ("zigma_linear_fwd", "zigma_conv_x_proj_fwd", "zigma_scale_reduce_bwd"
            "zigma_selective_scan_bwd_workspace_bytes", "zigma_causal_conv1d_bwd",
            "zigma_causal_conv1d_bwd_workspace_bytes", "zigma_add_norm_bwd", "zigma_add_norm_bwd_workspace_bytes",
            "zigma_strerror",
-           "zigma_cross_attn_bwd", "zigma_cross_attn_bwd_chunks", "zigma_abi_version", "zigma_last_kernel")
+           "zigma_cross_attn_bwd", "zigma_cross_attn_bwd_chunks", "zigma_patch_embed_fwd", "zigma_timestep_embed_fwd", "zigma_final_layer_fwd",
+           "zigma_skinny_linear_fwd", "zigma_abi_version", "zigma_last_kernel")
 
 _lib = None
 
@@ -162,7 +183,8 @@ def lib():
         for name, st in (("zigma_selective_scan_fwd", ScanParams), ("zigma_causal_conv1d_fwd", ConvParams),
                          ("zigma_add_norm_fwd", NormParams), ("zigma_dt_proj_softplus_fwd", DtProjParams),
                          ("zigma_selective_scan_bwd", ScanBwdParams), ("zigma_causal_conv1d_bwd", ConvBwdParams),
-                         ("zigma_add_norm_bwd", NormBwdParams), ("zigma_cross_attn_fwd", XAttnParams), ("zigma_cross_attn_bwd", XAttnBwdParams), ("zigma_x_proj_fwd", XProjParams),
+                         ("zigma_add_norm_bwd", NormBwdParams), ("zigma_cross_attn_fwd", XAttnParams), ("zigma_cross_attn_bwd", XAttnBwdParams), ("zigma_patch_embed_fwd", PatchEmbedParams),
+                         ("zigma_timestep_embed_fwd", TimestepEmbedParams), ("zigma_final_layer_fwd", FinalLayerParams), ("zigma_skinny_linear_fwd", SkinnyParams), ("zigma_x_proj_fwd", XProjParams),
                          ("zigma_linear_fwd", LinearParams), ("zigma_conv_x_proj_fwd", ConvXProjParams), ("zigma_scale_reduce_bwd", GlueBwdParams)):
             fn = getattr(L, name)
             fn.argtypes = [C.POINTER(st), vp]
@@ -179,7 +201,7 @@ def lib():
         L.zigma_strerror.restype = C.c_char_p
         L.zigma_abi_version.restype = C.c_int
         L.zigma_last_kernel.restype = C.c_char_p
-        if L.zigma_abi_version() != 7:
+        if L.zigma_abi_version() != 8:
             raise RuntimeError("zigma_amd: libzigma_hip.so ABI version mismatch")
         _lib = L
     return _lib

@@ -29,6 +29,7 @@ import torch.utils.checkpoint
 from torch import Tensor
 
 from .attention import attention_math, cross_attn, cross_attn_eligible, cross_attn_train
+from . import embed as _embed
 from .layernorm import RMSNorm, block_norm, glue_bwd_eligible, layer_norm_fn, rms_norm_fn, scale_reduce_bwd
 from .linear import gated_residual_eligible, linear, linear_eligible
 from .mamba_simple import Mamba
@@ -87,18 +88,25 @@ class PatchEmbed(nn.Module):
         self.num_patches = self.grid_size[0] * self.grid_size[1]
         self.proj = nn.Conv2d(in_chans, embed_dim, kernel_size=patch_size, stride=patch_size, bias=bias)
 
-    def forward(self, x):
+    def forward(self, x, pos=None):
+        """pos: optional (1, L, E) position table added to the tokens (ZigMa adds it right after, model_zigma.py:939-940): with it the
+        bf16 inference path is ONE kernel (zigma_patch_embed_fwd) instead of unfold + K = C p^2 GEMM + bias + add"""
         Bsz, Cin, H, W = x.shape
         p = self.patch_size[0]
+        no_grad = not (torch.is_grad_enabled() and (x.requires_grad or self.proj.weight.requires_grad or (pos is not None and pos.requires_grad)))
+        if no_grad and _embed.patch_embed_eligible(x, self.proj.weight, self.proj.bias, pos):
+            return _embed.patch_embed(x, self.proj.weight, self.proj.bias, pos)
         cols = x.reshape(Bsz, Cin, H // p, p, W // p, p).permute(0, 2, 4, 1, 3, 5).reshape(Bsz, -1, Cin * p * p)
-        return F.linear(cols, self.proj.weight.reshape(self.proj.weight.shape[0], -1), self.proj.bias)
+        tok = F.linear(cols, self.proj.weight.reshape(self.proj.weight.shape[0], -1), self.proj.bias)
+        return tok if pos is None else tok + pos
 
 
 class PatchEmbed_Video(PatchEmbed):
-    def forward(self, x):
+    def forward(self, x, pos=None):
         Bsz, T = x.shape[:2]
         tok = super().forward(x.reshape((Bsz * T,) + x.shape[2:]))
-        return tok.reshape(Bsz, -1, tok.shape[-1])
+        tok = tok.reshape(Bsz, -1, tok.shape[-1])
+        return tok if pos is None else tok + pos
 
 
 class CrossAttention(nn.Module):
@@ -196,8 +204,17 @@ class TimestepEmbedder(nn.Module):
 
     def forward(self, t):
         freqs = self._freqs if self._freqs.dtype == self.dtype else self._freqs.to(self.dtype)
-        t_freq = self.timestep_embedding(t, self.frequency_embedding_size, dtype=self.dtype, freqs=freqs)
-        return self.mlp(t_freq.to(dtype=self.dtype))
+        l1, l2 = self.mlp[0], self.mlp[2]
+        if self.frequency_embedding_size % 2 == 0 and _embed.timestep_embed_eligible(t, freqs):
+            t_freq = _embed.timestep_embed(t, freqs, self.frequency_embedding_size)       # one kernel instead of ~8 elementwise launches
+        else:
+            t_freq = self.timestep_embedding(t, self.frequency_embedding_size, dtype=self.dtype, freqs=freqs).to(dtype=self.dtype)
+        if _embed.skinny_linear_eligible(t_freq, l1.weight, l1.bias):
+            h = _embed.skinny_linear(t_freq, l1.weight, l1.bias)
+            if _embed.skinny_linear_eligible(h, l2.weight, l2.bias):
+                return _embed.skinny_linear(h, l2.weight, l2.bias, silu=True)                # SiLU folded into the staging of the second product
+            return l2(F.silu(h))
+        return self.mlp(t_freq)
 
 
 class LabelEmbedder(nn.Module):
@@ -230,6 +247,8 @@ class FinalLayer(nn.Module):
             self.adaLN_modulation = nn.Sequential(nn.SiLU(), nn.Linear(hidden_size, 2 * hidden_size, bias=True))
 
     def forward(self, x, c=None):
+        if c is None and _embed.final_layer_eligible(x, self.linear.weight, self.linear.bias):
+            return _embed.final_layer(x, self.linear.weight, self.linear.bias, self.norm_final.eps)      # LayerNorm + projection in one pass
         x = layer_norm_fn(x, None, None, eps=self.norm_final.eps)
         if c is not None:
             shift, scale = self.adaLN_modulation(c).chunk(2, dim=1)
@@ -535,7 +554,8 @@ class ZigMa(nn.Module):
         """x: (N, C, H, W) [or (N, T, C, H, W)] latents; t: (N,) diffusion times; y: (N,) labels or (N, n_ctx, d_ctx) text."""
         in_dtype = hidden_states.dtype
         pdtype = self.x_embedder.proj.weight.dtype
-        hidden_states = self.x_embedder(hidden_states.to(pdtype))               # (N, T, D)
+        pos = self.pos_embed if self.use_pe in (1, 2) else None
+        hidden_states = self.x_embedder(hidden_states.to(pdtype), pos=pos)      # (N, T, D), position table added
         _B, _T, _D = hidden_states.shape
 
         t = (t * 1000.0).to(hidden_states)
@@ -548,8 +568,6 @@ class ZigMa(nn.Module):
         else:
             c = t
 
-        if self.use_pe in (1, 2):
-            hidden_states = hidden_states + self.pos_embed
         if self.video_frames > 0 and self.tpe:
             K = _T // self.video_frames
             hidden_states = (hidden_states.view(_B, self.video_frames, K, _D)
@@ -616,7 +634,11 @@ class ZigMa(nn.Module):
             self._cond_cache = cache
         _, Wm, bm, Wkv = cache
         n = len(blocks)
-        mods = F.linear(F.silu(c), Wm, bm).view(c.shape[0], n, -1).unbind(1)       # n x (B, 3E | 6E), row pitch n*6E
+        if _embed.skinny_linear_eligible(c, Wm, bm):       # <= 64 samples against n * 6E weight rows: weight-streaming MFMA kernel
+            mods_all = _embed.skinny_linear(c, Wm, bm, silu=True)
+        else:
+            mods_all = F.linear(F.silu(c), Wm, bm)
+        mods = mods_all.view(c.shape[0], n, -1).unbind(1)                           # n x (B, 3E | 6E), row pitch n*6E
         kvs = None
         if self.has_text:
             inner = blocks[0].msa.to_k.weight.shape[0]
