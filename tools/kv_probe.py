@@ -1,0 +1,24 @@
+"""The batched text K / V projection of all blocks (M = 64 x 77 = 4928 rows, K = 640, N = 18 x 2 x 512) on linear4w_kernel with the rows padded to
+5120, against the library on the 4928 rows.  Measured: 138.3 vs 133.4 us, bit-identical -> the library keeps this one."""
+import os, sys, torch, json
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+os.environ["ZIGMA_LINEAR"] = "all"
+from zigma_amd.linear import linear
+from zigma_amd import _lib
+F = torch.nn.functional
+dev, dt = "cuda", torch.bfloat16
+torch.manual_seed(0)
+K, N = 640, 18432
+w = (torch.randn(N, K, device=dev) * K ** -0.5).to(dt)
+xp = torch.zeros(5120, K, device=dev, dtype=dt); xp[:4928] = torch.randn(4928, K, device=dev).to(dt)
+x = xp[:4928]
+def timeit(fn):
+    for _ in range(3): fn()
+    torch.cuda.synchronize(); e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(20): fn()
+    e1.record(); torch.cuda.synchronize(); return e0.elapsed_time(e1) / 20 * 1e3
+a = linear(xp, w); k4 = _lib.last_kernel()
+b = F.linear(x, w)
+print(json.dumps(dict(own_padded_us=timeit(lambda: linear(xp, w)), kernel=k4, lib_us=timeit(lambda: F.linear(x, w)), same=bool(torch.equal(a[:4928], b)),
+                      maxdiff=float((a[:4928].float() - b.float()).abs().max()))))
