@@ -3,6 +3,8 @@ import json, os, sys, time, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from bench import WORKLOADS, build_model, make_inputs
 from zigma_amd.transport import create_transport
+import zigma_amd.wgrad as _wg
+_wg.SPLIT_WGRAD = os.environ.get("SPLIT_WGRAD", "1") == "1"      # A/B knob
 dev = torch.device("cuda", 0)
 wl = WORKLOADS["readme_text_b64"]
 B = int(os.environ.get("B", 32))

@@ -16,6 +16,7 @@ import torch.nn.functional as F
 
 from .linear import gated_residual_eligible, linear, linear_eligible
 from .selective_scan_interface import mamba_inner_tok
+from .wgrad import linear_train
 
 NO_COPY_TEMPORAL = True      # video "t" layers on strided views (False: the transposing-copy form; A/B in the tests)
 
@@ -261,4 +262,4 @@ class Mamba(nn.Module):
         """in_proj / out_proj: the hand-written MFMA kernel where it applies (zigma_amd.linear), the library otherwise"""
         if linear_eligible(x, lin.weight, lin.bias):
             return linear(x, lin.weight, lin.bias)
-        return F.linear(x, lin.weight, lin.bias)
+        return linear_train(x, lin.weight, lin.bias)       # (F.linear; under autograd with the slab-wise weight gradient, zigma_amd/wgrad.py)

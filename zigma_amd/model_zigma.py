@@ -33,6 +33,7 @@ from . import embed as _embed
 from .layernorm import RMSNorm, block_norm, glue_bwd_eligible, layer_norm_fn, rms_norm_fn, scale_reduce_bwd
 from .linear import gated_residual_eligible, linear, linear_eligible
 from .mamba_simple import Mamba
+from .wgrad import linear_train
 from .scan_paths import hilbert_path, reverse_permut_np, zigzag_path
 
 
@@ -125,7 +126,7 @@ class CrossAttention(nn.Module):
     def _proj(x, lin):
         if linear_eligible(x, lin.weight, lin.bias):
             return linear(x, lin.weight, lin.bias)
-        return F.linear(x, lin.weight, lin.bias)
+        return linear_train(x, lin.weight, lin.bias)       # (F.linear; under autograd with the slab-wise weight gradient, zigma_amd/wgrad.py)
 
     def _proj_out(self, o, residual, gate):
         """to_out (+ dropout); with residual / gate the block's gated branch add `residual + gate * to_out(o)` (reference Block,

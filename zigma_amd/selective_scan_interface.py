@@ -23,6 +23,7 @@ import torch.nn.functional as F
 
 from . import _lib
 from .causal_conv1d_interface import causal_conv1d_raw, conv_bwd_tok
+from .wgrad import wgrad
 
 
 SPLIT_SMALL_BATCH = True     # tools/latency_probe.py flips this to measure the effect of the small-batch sequence split
@@ -429,10 +430,10 @@ class MambaInnerTokFn(torch.autograd.Function):
         ctx.ck = None
         dd2 = ddelta.reshape(-1, Di)
         dx_dbl[:, :, :R] = (dd2 @ dt_proj_w).reshape(Bsz, L, R)                  # d(x_dbl[:, :R]) = ddelta @ W_dt
-        d_dt_w = dd2.t() @ x_dbl.reshape(-1, R + 2 * N)[:, :R]                     # (Di, R)
+        d_dt_w = wgrad(dd2, x_dbl.reshape(-1, R + 2 * N)[:, :R].contiguous())       # (Di, R)  token-slab GEMMs (zigma_amd/wgrad.py)
         dxd = dx_dbl.to(xz.dtype).reshape(-1, R + 2 * N)
         du = torch.addmm(du.reshape(-1, Di), dxd, x_proj_w).reshape(Bsz, L, Di)    # x_dbl = u @ W_x^T
-        d_x_w = dxd.t() @ u.reshape(-1, Di)                                        # (R + 2N, Di)
+        d_x_w = wgrad(dxd, u.reshape(-1, Di))                                      # (R + 2N, Di)
         _, d_cw, d_cb = conv_bwd_tok(x_half, conv_w, conv_b, du, True, ctx.perm, dx=dxz[:, :, :Di], reset_period=rp)
         return (dxz, d_cw.to(conv_w.dtype).reshape(conv_w.shape), None if d_cb is None else d_cb.to(conv_b.dtype),
                 d_x_w.to(x_proj_w.dtype), d_dt_w.to(dt_proj_w.dtype), dA.to(A.dtype), dD.to(D.dtype),

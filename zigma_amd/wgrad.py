@@ -1,0 +1,65 @@
+"""Weight gradients of the block's projections for the training path: dW = dY^T X with the TOKENS as the contraction dimension
+(M = batch x seqlen = 65 536 at the headline shape against outputs of 72 x 1280 ... 2560 x 640 elements).
+
+The reference leaves these to autograd's linear backward (one GEMM each); as ONE library GEMM they are 5 ... 100 output tiles for 256
+CUs and run at 0.03 ... 0.5 PFLOP/s (tools/wgrad_split_probe.py: in_proj 450 us, to_q 259 us, x_proj 227 us).  Split along the tokens
+into S slabs as a BATCHED GEMM (the slab index is the library's batch dimension) the same products fill the chip; the S partial
+results (bf16, like a GEMM output) are added in fp32: in_proj 332 us, out_proj 303 -> 149, to_q 259 -> 76, to_out 271 -> 66,
+x_proj 227 -> 72, dt_proj 205 -> 64 us — 17 ms of a 122 ms training step.  `LinearTrainFn` is F.linear with that backward."""
+import torch
+import torch.nn.functional as F
+
+SPLIT_WGRAD = True        # False: one GEMM (A/B in tools/train_probe.py)
+
+
+def _slabs(m, n, k):
+    """number of token slabs: enough (128 x 128)-tile workgroups for ~2 per CU, a power of two dividing m, slabs of >= 256 rows"""
+    tiles = max(1, -(-n // 128) * -(-k // 128))
+    s = 8
+    while s < 64 and s * tiles < 512:
+        s *= 2
+    while s > 1 and (m % s or (m // s) < 256 or (m // s) % 8):
+        s //= 2
+    return s
+
+
+def wgrad(dy2, x2):
+    """dy2 (m, n), x2 (m, k), same 16-bit dtype -> dy2^T x2 (n, k) in that dtype (fp32 sum of the slab products)"""
+    m, n = dy2.shape
+    k = x2.shape[1]
+    s = _slabs(m, n, k) if (SPLIT_WGRAD and dy2.is_cuda and dy2.dtype in (torch.bfloat16, torch.float16)) else 1
+    if s <= 1:
+        return dy2.t() @ x2
+    dy3 = dy2.reshape(s, m // s, n)
+    x3 = x2.reshape(s, m // s, k)
+    return torch.bmm(dy3.transpose(1, 2), x3).sum(0, dtype=torch.float32).to(dy2.dtype)
+
+
+class LinearTrainFn(torch.autograd.Function):
+    """F.linear whose weight gradient is formed slab-wise (see the module docstring); dX and dbias as autograd forms them."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        ctx.save_for_backward(x, weight)
+        ctx.has_bias = bias is not None
+        return F.linear(x, weight, bias)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight = ctx.saved_tensors
+        dy2 = dy.reshape(-1, dy.shape[-1])
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = (dy2 @ weight).view(x.shape)
+        if ctx.needs_input_grad[1]:
+            dw = wgrad(dy2, x.reshape(-1, x.shape[-1]))
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            db = dy2.sum(0)
+        return dx, dw, db
+
+
+def linear_train(x, weight, bias=None):
+    """differentiable projection of the training path: the slab-wise weight gradient where it pays (many tokens), F.linear otherwise"""
+    if x.is_cuda and x.dtype in (torch.bfloat16, torch.float16) and x.numel() // x.shape[-1] >= 4096 and torch.is_grad_enabled():
+        return LinearTrainFn.apply(x, weight, bias)
+    return F.linear(x, weight, bias)
