@@ -275,6 +275,7 @@ class Pending:
 # pre-attention add + norm 68 -> 47, and with to_out's gated add: to_out 63 -> 78, pre-mixer add + norm 119 -> 102 — time moves from
 # the HBM-bound norm kernels into the projection epilogues, the forward is 0.1-0.3 % faster.
 FUSE_OUT_PROJ_ADD = True       # (module-level knob for tests / tools; no environment switch)
+FUSE_OUT_PROJ_ADD_NO_TEXT = True     # the same for blocks without the attention branch (tools/outproj_notext_ab.py: 14.82 -> 14.78 ms on config 3's model)
 
 
 class Block(nn.Module):
@@ -308,14 +309,16 @@ class Block(nn.Module):
         _, residual, n, xm = block_norm(pend.base, self.norm.weight, self.norm.bias, residual, self.norm.eps, is_rms,
                                         residual_in_fp32=self.residual_in_fp32, branch=pend.branch, gate=pend.gate,
                                         shift=mod[:, 0:E], scale=mod[:, E:2 * E])
-        # (text blocks only: there the following LayerNorm call shrinks to one read + one write; without the attention branch the
-        # library out_proj + the add inside the next block's norm measured 0.7-0.9 % faster on configs 3 and 4)
+        # (with the attention branch the following LayerNorm call shrinks to one read + one write; without it the next block's norm reads one
+        # tensor instead of base + branch — round 2's 8-wave kernel lost 0.7-0.9 % there against the library, the 4-wave one wins 0.25 %)
         if FUSE_OUT_PROJ_ADD and self.has_text and self.mixer.out_add_fusable(n, mod[:, 2 * E:3 * E]):
             # n + gate_msa * mixer(xm) in out_proj's epilogue (own projection kernel): the following norm reads one tensor, writes one
             h = self.mixer(xm, residual=n, gate=mod[:, 2 * E:3 * E])
             _, _, _, xa = block_norm(h, None, None, None, self.norm_msa.eps, False, residual_in_fp32=False,
                                      shift=mod[:, 3 * E:4 * E], scale=mod[:, 4 * E:5 * E], want_x=False, want_y=False, want_res_out=False)
             return Pending(self.msa(xa, text=text, mask=None, kv=kv, residual=h, gate=mod[:, 5 * E:6 * E])), residual
+        if FUSE_OUT_PROJ_ADD_NO_TEXT and not self.has_text and self.mixer.out_add_fusable(n, mod[:, 2 * E:3 * E]):
+            return Pending(self.mixer(xm, residual=n, gate=mod[:, 2 * E:3 * E])), residual
         mix = self.mixer(xm)
         if not self.has_text:
             return Pending(n, mix, mod[:, 2 * E:3 * E]), residual
