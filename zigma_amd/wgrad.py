@@ -60,6 +60,7 @@ class LinearTrainFn(torch.autograd.Function):
 
 def linear_train(x, weight, bias=None):
     """differentiable projection of the training path: the slab-wise weight gradient where it pays (many tokens), F.linear otherwise"""
-    if x.is_cuda and x.dtype in (torch.bfloat16, torch.float16) and x.numel() // x.shape[-1] >= 4096 and torch.is_grad_enabled():
+    if (x.is_cuda and x.dtype in (torch.bfloat16, torch.float16) and weight.dtype == x.dtype and (bias is None or bias.dtype == x.dtype)
+            and x.numel() // x.shape[-1] >= 4096 and torch.is_grad_enabled() and not torch.is_autocast_enabled()):
         return LinearTrainFn.apply(x, weight, bias)
     return F.linear(x, weight, bias)
