@@ -400,3 +400,22 @@ def test_sequence_split_policy():
     for b in range(1, 11):
         c = split_chunk_len(b, 1280, 1024)
         assert c % 16 == 0 and c >= 32 and -(-1024 // c) >= 2
+
+
+def test_linear_train_fn_matches_autograd_and_slab_rule():
+    """zigma_amd.wgrad: LinearTrainFn (F.linear with the slab-wise weight gradient) gives autograd's gradients; the slab rule returns a
+    power of two that divides the rows into slabs of at least 256 rows (multiples of 8)."""
+    from zigma_amd.wgrad import LinearTrainFn, _slabs, wgrad
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(3, 40, 24, generator=g, requires_grad=True)
+    w = torch.randn(16, 24, generator=g, requires_grad=True)
+    b = torch.randn(16, generator=g, requires_grad=True)
+    dy = torch.randn(3, 40, 16, generator=g)
+    ref = torch.autograd.grad(torch.nn.functional.linear(x, w, b), (x, w, b), dy)
+    got = torch.autograd.grad(LinearTrainFn.apply(x, w, b), (x, w, b), dy)
+    for a, r in zip(got, ref):
+        assert torch.allclose(a, r, rtol=1e-5, atol=1e-5)
+    assert torch.allclose(wgrad(dy.reshape(-1, 16), x.detach().reshape(-1, 24)), ref[1], rtol=1e-5, atol=1e-5)
+    for m, n, k in ((65536, 2560, 640), (65536, 72, 1280), (65536, 1280, 40), (4096, 512, 640), (1000, 64, 64), (256, 640, 640)):
+        s = _slabs(m, n, k)
+        assert s >= 1 and (s & (s - 1)) == 0 and (s == 1 or (m % s == 0 and m // s >= 256 and (m // s) % 8 == 0)), (m, n, k, s)
