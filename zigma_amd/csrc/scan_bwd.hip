@@ -230,11 +230,19 @@ __global__ __launch_bounds__(64 * NW, 2) void scan_bwd_kernel(const zigma_scan_b
         // ---- forward recompute of the 16 states -----------------------------------------------------------------
         v2f hsA[LT], hsB[LT];
         {
+            // operands one step ahead in registers (2 waves per SIMD do not hide an LDS round trip per step)
             v2f hhA = h0A, hhB = h0B;
+            float dvn = s_dv[0][lane], un = s_u[0][lane];
+            v4f Bn = *reinterpret_cast<const v4f *>(&s_bc[0][0][n0]);
 #pragma unroll
             for (int s = 0; s < LT; ++s) {
-                const float dv = s_dv[s][lane], du = dv * s_u[s][lane];
-                const v4f Bv = *reinterpret_cast<const v4f *>(&s_bc[s][0][n0]);
+                const float dv = dvn, du = dv * un;
+                const v4f Bv = Bn;
+                if (s + 1 < LT) {
+                    dvn = s_dv[s + 1][lane];
+                    un = s_u[s + 1][lane];
+                    Bn = *reinterpret_cast<const v4f *>(&s_bc[s + 1][0][n0]);
+                }
                 const v2f dtv = {dv, dv}, duv = {du, du};
                 const v2f xA = a2A * dtv, xB = a2B * dtv;
                 const v2f eA = {fast_exp2(xA.x), fast_exp2(xA.y)}, eB = {fast_exp2(xB.x), fast_exp2(xB.y)};
@@ -245,14 +253,21 @@ __global__ __launch_bounds__(64 * NW, 2) void scan_bwd_kernel(const zigma_scan_b
             }
         }
         // ---- reverse recurrence + gradients (two states per instruction) ----------------------------------------------
+        float rdv = s_dv[LT - 1][lane], ru = s_u[LT - 1][lane], rg = s_g[LT - 1][lane];
+        v4f rB = *reinterpret_cast<const v4f *>(&s_bc[LT - 1][0][n0]), rC = *reinterpret_cast<const v4f *>(&s_bc[LT - 1][1][n0]);
 #pragma unroll
         for (int g = NG - 1; g >= 0; --g) {
 #pragma unroll
             for (int si = 3; si >= 0; --si) {
                 const int s = g * 4 + si;
-                const float dv = s_dv[s][lane], uu = s_u[s][lane], gg = s_g[s][lane];
+                const float dv = rdv, uu = ru, gg = rg;
                 const float du = dv * uu;
-                const v4f Bv = *reinterpret_cast<const v4f *>(&s_bc[s][0][n0]), Cv = *reinterpret_cast<const v4f *>(&s_bc[s][1][n0]);
+                const v4f Bv = rB, Cv = rC;
+                if (s > 0) {        // the previous step's operands (the sweep runs backwards) are requested before this step's arithmetic
+                    rdv = s_dv[s - 1][lane]; ru = s_u[s - 1][lane]; rg = s_g[s - 1][lane];
+                    rB = *reinterpret_cast<const v4f *>(&s_bc[s - 1][0][n0]);
+                    rC = *reinterpret_cast<const v4f *>(&s_bc[s - 1][1][n0]);
+                }
                 const v2f dtv = {dv, dv}, duv = {du, du}, ggv = {gg, gg};
                 const v2f xA = a2A * dtv, xB = a2B * dtv;
                 const v2f eA = {fast_exp2(xA.x), fast_exp2(xA.y)}, eB = {fast_exp2(xB.x), fast_exp2(xB.y)};
