@@ -1,7 +1,15 @@
 """Stand-alone timing of the scan backward kernel at the headline shape (with the backward's own forward phase, and with
 checkpoints handed over by the forward kernel)."""
 import os, sys, torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+PROBE = int(os.environ.get("PROBE", 0))      # phase-skipping timing probe: a probe build with -DZIGMA_SCANBWD_PROBE=<mask> (results wrong)
+if PROBE:
+    PROBE_LIB = os.path.join(ROOT, "tools", f"libzigma_scanbwd_probe{PROBE}.so")
+    if not os.path.exists(PROBE_LIB):           # (build them in the container before the GPU call)
+        from zigma_amd import build as zbuild
+        zbuild.build(verbose=False, lib=PROBE_LIB, extra_flags=(f"-DZIGMA_SCANBWD_PROBE={PROBE}",))
+    os.environ["ZIGMA_AMD_LIB"] = PROBE_LIB
 from zigma_amd.selective_scan_interface import scan_bwd_tok, scan_raw
 dev, dt = "cuda", torch.bfloat16
 B, L, Di, N = int(os.environ.get("B", 64)), 1024, 1280, 16
@@ -20,5 +28,6 @@ def timeit(fn, iters=5):
     e0.record()
     for _ in range(iters): fn()
     e1.record(); torch.cuda.synchronize(); return e0.elapsed_time(e1) / iters * 1e3
+print(f"probe mask {PROBE}:") if PROBE else None
 print("scan bwd, own checkpoints     ", round(timeit(lambda: scan_bwd_tok(u, delta, A, Bm, Cm, D, z, db, dout, out, True)), 1), "us")
 print("scan bwd, forward's checkpoints", round(timeit(lambda: scan_bwd_tok(u, delta, A, Bm, Cm, D, z, db, dout, out, True, checkpoints=ck)), 1), "us")

@@ -52,6 +52,13 @@ __global__ __launch_bounds__(64 * NW, 2) void scan_bwd_kernel(const zigma_scan_b
     const int n0 = wave * 4;
     const int n_tiles = (L + LT - 1) / LT;
     const bool has_z = p.z != nullptr, sp_on = p.delta_softplus != 0;
+    // timing probes (results wrong; probe builds of tools/bwd_probe.py only, compile-time so that the shipped loops stay branch-free):
+    // -DZIGMA_SCANBWD_PROBE=mask: 1 no cross-channel reduction, 2 no barriers, 4 no du / ddelta / dz stores, 8 no forward recompute
+#ifdef ZIGMA_SCANBWD_PROBE
+    constexpr int probe = ZIGMA_SCANBWD_PROBE;
+#else
+    constexpr int probe = 0;
+#endif
 
     float a2[4], An[4];
 #pragma unroll
@@ -225,7 +232,7 @@ __global__ __launch_bounds__(64 * NW, 2) void scan_bwd_kernel(const zigma_scan_b
             fetch_bwd(t - 1);
             if (t > 1) load_tabs(t - 2);
         }
-        __syncthreads();
+        if (!(probe & 2)) __syncthreads();
 
         // ---- forward recompute of the 16 states -----------------------------------------------------------------
         v2f hsA[LT], hsB[LT];
@@ -235,7 +242,7 @@ __global__ __launch_bounds__(64 * NW, 2) void scan_bwd_kernel(const zigma_scan_b
             float dvn = s_dv[0][lane], un = s_u[0][lane];
             v4f Bn = *reinterpret_cast<const v4f *>(&s_bc[0][0][n0]);
 #pragma unroll
-            for (int s = 0; s < LT; ++s) {
+            for (int s = 0; s < ((probe & 8) ? 1 : LT); ++s) {
                 const float dv = dvn, du = dv * un;
                 const v4f Bv = Bn;
                 if (s + 1 < LT) {
@@ -285,6 +292,7 @@ __global__ __launch_bounds__(64 * NW, 2) void scan_bwd_kernel(const zigma_scan_b
                 *reinterpret_cast<v4f *>(red_b + si * kRedPitch + lane * 4) = v4f{pBA.x, pBA.y, pBB.x, pBB.y};
                 *reinterpret_cast<v4f *>(red_c + si * kRedPitch + lane * 4) = v4f{pCA.x, pCA.y, pCB.x, pCB.y};
             }
+            if constexpr ((probe & 1) != 0) continue;
             // cross-channel sums of the group: lane -> (half wave, dB | dC, step, state); 32 values each, then fold the halves
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
@@ -303,7 +311,7 @@ __global__ __launch_bounds__(64 * NW, 2) void scan_bwd_kernel(const zigma_scan_b
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();                       // next group overwrites the buffer
         }
-        __syncthreads();
+        if (!(probe & 2)) __syncthreads();
         // ---- epilogue: own rows -----------------------------------------------------------------------------------
 #pragma unroll
         for (int i = 0; i < RPT; ++i) {
@@ -317,7 +325,7 @@ __global__ __launch_bounds__(64 * NW, 2) void scan_bwd_kernel(const zigma_scan_b
             }
             const float duo = __builtin_fmaf(dvr[i], SP, gr[i] * Dv);
             const float dd = __builtin_fmaf(ur[i], SP, SA) * sgr[i];
-            if (k < L) {
+            if (k < L && !(probe & 4)) {
                 buf_st<IO>(from_float<IO>(duo), du_rs, lane_off, k * du_ls);
                 buf_st<IO>(from_float<IO>(dd), dd_rs, lane_off, k * dd_ls);
                 db_acc += dd;
