@@ -34,8 +34,7 @@ def fused_then_dt():
 
 F = lambda fl: (lambda: conv_x_proj(x_half, cw, cb, w, perm, _flags=fl))
 variants = {"separate": separate, "separate_dt": separate_dt, "fused_then_dt": fused_then_dt,
-            "fused_dt": lambda: conv_x_proj(x_half, cw, cb, w, perm, dt_weight=dw, dt_bias=db),
-            "fused_dt_8w": lambda: conv_x_proj(x_half, cw, cb, w, perm, _flags=2, dt_weight=dw, dt_bias=db), "fused": F(0), "fused_3stage": F(1), "fused_8w": F(2), "fused_8w_3stage": F(3),
+            "fused": F(0), "fused_3stage": F(1), "fused_8w": F(2), "fused_8w_3stage": F(3),
             "probe_nostore": F(4), "probe_noconv": F(8), "probe_neither": F(12)}
 outs = {k: f() for k, f in variants.items()}
 torch.cuda.synchronize()

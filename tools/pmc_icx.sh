@@ -1,0 +1,20 @@
+#!/bin/bash
+# PMC counters for in_conv_x_proj_kernel alone (separate passes; no trace domains combined with --pmc).  Driver: tools/icx_one.py
+R=${GRAFT_REPO_ROOT:-$PWD}
+cd /tmp && export TMPDIR=/tmp
+for pass in "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY" \
+            "SQ_ACTIVE_INST_ANY SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_INSTS_VMEM GRBM_GUI_ACTIVE" \
+            "SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES" "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum"; do
+  tag=icx_$(echo $pass | cut -d' ' -f1)
+  timeout 120 rocprofv3 --pmc $pass --output-format csv -d $R/gpurun_out/pmc_$tag -o pmc -- python $R/tools/icx_one.py > $R/gpurun_out/pmc_$tag.log 2>&1
+done
+cd $R
+python - <<'PY'
+import csv, glob, collections
+for f in sorted(glob.glob("gpurun_out/pmc_icx_*/**/*counter_collection.csv", recursive=True)):
+    agg=collections.defaultdict(list)
+    for r in csv.DictReader(open(f)):
+        if "in_conv_x_proj" in r["Kernel_Name"]:
+            agg[(r["Kernel_Name"][:40], r["Counter_Name"])].append(float(r["Counter_Value"]))
+    for k,v in agg.items(): print(f"{k[0]:42s} {k[1]:28s} n={len(v):3d} mean={sum(v)/len(v):.6g}")
+PY

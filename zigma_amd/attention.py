@@ -45,12 +45,59 @@ def _heads(t, H):
     return t.view(t.shape[0], t.shape[1], H, -1).transpose(1, 2)
 
 
-def attention_math(q, k, v, heads, scale):
-    """softmax(scale q k^T) v per head with batched GEMMs and ATen ops (no fused SDPA): the fallback for operands the kernel does not
-    take, differentiable by autograd"""
+def _attention_math_plain(q, k, v, heads, scale):
     qh, kh, vh = _heads(q, heads), _heads(k, heads), _heads(v, heads)
     p = torch.softmax(torch.matmul(qh, kh.transpose(-1, -2)).float() * scale, dim=-1).to(q.dtype)
     return torch.matmul(p, vh).transpose(1, 2).reshape(q.shape)
+
+
+ATTN_MATH_CHUNK_ELEMS = 2 ** 26      # fp32 probabilities alive at a time (256 MB): (B, H, L, n_ctx) is walked in batch chunks of this size
+
+
+def _batch_chunks(q, k, heads):
+    per_sample = max(heads * q.shape[1] * k.shape[1], 1)
+    step = max(1, ATTN_MATH_CHUNK_ELEMS // per_sample)
+    return [slice(i, min(i + step, q.shape[0])) for i in range(0, q.shape[0], step)]
+
+
+class _AttentionMathFn(torch.autograd.Function):
+    """attention_math under autograd without keeping the (B, H, L, n_ctx) probabilities of every layer alive: only q, k, v are
+    saved, the backward recomputes the probabilities chunk by chunk (the memory behaviour of the reference's fused attention)."""
+
+    @staticmethod
+    def forward(ctx, q, k, v, heads, scale):
+        ctx.save_for_backward(q, k, v)
+        ctx.heads, ctx.scale = heads, scale
+        out = torch.empty_like(q)
+        for sl in _batch_chunks(q, k, heads):
+            out[sl] = _attention_math_plain(q[sl], k[sl], v[sl], heads, scale)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        q, k, v = ctx.saved_tensors
+        dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+        for sl in _batch_chunks(q, k, ctx.heads):
+            with torch.enable_grad():
+                qc, kc, vc = (t[sl].detach().requires_grad_(True) for t in (q, k, v))
+                o = _attention_math_plain(qc, kc, vc, ctx.heads, ctx.scale)
+            dq[sl], dk[sl], dv[sl] = torch.autograd.grad(o, (qc, kc, vc), dout[sl])
+        return dq, dk, dv, None, None
+
+
+def attention_math(q, k, v, heads, scale):
+    """softmax(scale q k^T) v per head with batched GEMMs and ATen ops (no fused SDPA): the fallback for operands the kernel does not
+    take.  Walks the batch in chunks so that at most ATTN_MATH_CHUNK_ELEMS fp32 probabilities exist at a time, and under autograd
+    saves q, k, v only (the probabilities are recomputed in the backward)."""
+    if torch.is_grad_enabled() and (q.requires_grad or k.requires_grad or v.requires_grad):
+        return _AttentionMathFn.apply(q, k, v, heads, scale)
+    chunks = _batch_chunks(q, k, heads)
+    if len(chunks) == 1:
+        return _attention_math_plain(q, k, v, heads, scale)
+    out = torch.empty_like(q)
+    for sl in chunks:
+        out[sl] = _attention_math_plain(q[sl], k[sl], v[sl], heads, scale)
+    return out
 
 
 def cross_attn_bwd(q, k, v, dout, heads, scale=None):

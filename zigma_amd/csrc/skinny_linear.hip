@@ -140,18 +140,17 @@ extern "C" int zigma_skinny_linear_fwd(const zigma_skinny_params_t *pp, void *st
     const dim3 grid(want < 256 ? want : 256), block(64 * kSkWaves);      // one workgroup per CU (LDS), persistent over the strips: x is staged once
     const size_t lds = static_cast<size_t>(64) * (p.k + 8) * 2;
     hipStream_t stream = static_cast<hipStream_t>(stream_);
-    // (more than 64 KB of dynamic LDS needs a process-wide function attribute: set once per instantiation)
+    // (more than 64 KB of dynamic LDS needs a function attribute; it applies to the CURRENT device only, so it is set per call —
+    // a host-side table update, no device work — instead of once per process: a second GPU driven by the same process would
+    // otherwise launch without it and fail)
 #define ZIGMA_SK_CASE(KS_)                                                                                                     \
     case KS_: {                                                                                                                \
-        static bool big_lds_set[2] = {false, false};                                                                           \
         const int v = p.flags & 1;                                                                                             \
         const void *fn = v ? reinterpret_cast<const void *>(skinny_linear_kernel<true, KS_>)                                   \
                            : reinterpret_cast<const void *>(skinny_linear_kernel<false, KS_>);                                 \
-        if (lds > 65536 && !big_lds_set[v]) {                                                                                  \
-            if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)) != hipSuccess)     \
-                return ZIGMA_ERR_LAUNCH;                                                                                       \
-            big_lds_set[v] = true;                                                                                             \
-        }                                                                                                                      \
+        if (lds > 65536 &&                                                                                                     \
+            hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)) != hipSuccess)         \
+            return ZIGMA_ERR_LAUNCH;                                                                                                                      \
         if (v) hipLaunchKernelGGL((skinny_linear_kernel<true, KS_>), grid, block, lds, stream, p);                             \
         else hipLaunchKernelGGL((skinny_linear_kernel<false, KS_>), grid, block, lds, stream, p);                              \
         break;                                                                                                                 \

@@ -106,7 +106,7 @@ def final_layer_eligible(x, weight, bias):
         return False
     if bias is not None and (bias.dtype != BF16 or not bias.is_contiguous()):
         return False
-    return not (torch.is_grad_enabled() and (x.requires_grad or weight.requires_grad))
+    return not (torch.is_grad_enabled() and (x.requires_grad or weight.requires_grad or (bias is not None and bias.requires_grad)))
 
 
 def final_layer(x, weight, bias, eps):

@@ -7,13 +7,13 @@ from . import _lib
 
 import os
 
-# Which projections run on zigma_linear_fwd.  Measured at the headline shapes, own kernel vs hipBLASLt in us (stand-alone:
-# tools/linear_probe.py, profiles/r02_linear_probe.jsonl; inside the forward: profiles/r02_b_bench_kernel_stats.csv):
-#   to_out (bias) 55-60 vs 66-68;  out_proj 119-124 vs 115-118 stand-alone, 150 (WITH the block's gated add in its epilogue) vs 127
-#   in the forward;  to_q 47.5 vs 42.4;  in_proj 241 vs 188-194.
-#   "auto" (default): the projections whose epilogue the library cannot fuse — to_out (bias + gated add) and, in text blocks,
-#   out_proj (gated add; model_zigma.FUSE_OUT_PROJ_ADD) — the rest (in_proj, to_q) on the library;  "all": every eligible
-#   projection on the own kernel (the forward is then ~5 % slower);  "off": library only.
+# Which projections run on zigma_linear_fwd.  Measured at the headline shapes (M = 65 536 tokens), own 4-wave kernel (csrc/linear4w.hip)
+# vs hipBLASLt in us (profiles/r03_e_linear4w_probe.jsonl, r03_n_linear4w_epilogue_probe.jsonl; in the forward r03_t_bench_kernel_stats.csv):
+#   out_proj + gated add 122 vs 116 + the add in the norm kernel;  to_out + bias + gated add 54 (67 in the forward) vs 70;
+#   to_q 46-47 vs 44-47 (a tie);  the whole in_proj (N = 2560) 222 vs 200 — which is why round 4 no longer runs it as ONE projection:
+#   its x half lives inside zigma_in_conv_x_proj_fwd (selective_scan_interface.in_conv_x_proj) and only the z half (N = 1280) is a GEMM.
+#   "auto" (default): every projection of the inference path the own kernel serves at least as fast as the library (to_q, to_out,
+#   out_proj with the block's gated add, the z half of in_proj);  "all": every eligible projection;  "off": library only.
 LINEAR_POLICY = os.environ.get("ZIGMA_LINEAR", "auto")
 
 

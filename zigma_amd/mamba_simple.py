@@ -15,7 +15,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from .linear import gated_residual_eligible, linear, linear_eligible
-from .selective_scan_interface import mamba_inner_tok
+from .selective_scan_interface import mamba_inner_hidden, mamba_inner_hidden_eligible, mamba_inner_tok
 from .wgrad import linear_train
 
 NO_COPY_TEMPORAL = True      # video "t" layers on strided views (False: the transposing-copy form; A/B in the tests)
@@ -203,13 +203,21 @@ class Mamba(nn.Module):
         if inference_params is not None:
             raise NotImplementedError("zigma_amd: recurrent decoding is out of scope (ZigMa never passes inference_params)")
         batch, seqlen, _ = hidden_states.shape
-        xz = self._proj(hidden_states, self.in_proj)                                  # (B, L, 2*Di) token-major
         A, Dp, dtb = self._scan_consts("")
+        st = self.scan_type
+        if self.in_proj.bias is None and (st == "v1" or (st.startswith(("zigzagN", "hilbertN", "randomN")) and not self.extras)):
+            # single-sweep layers at inference: `xz` is never formed — the x half of in_proj runs inside the conv + x_proj kernel
+            # (zigma_in_conv_x_proj_fwd), the z half is a projection of its own
+            perm = None if st == "v1" else self._perm
+            if mamba_inner_hidden_eligible(hidden_states, self.in_proj.weight, self.conv1d.weight, self.conv1d.bias, self.x_proj.weight, perm):
+                return mamba_inner_hidden(hidden_states, self.in_proj.weight, self.conv1d.weight, self.conv1d.bias, self.x_proj.weight,
+                                          self.dt_proj.weight, A, Dp, dtb, perm=perm,
+                                          out_rows=self._out_rows if perm is not None else None, delta_softplus=True)
+        xz = self._proj(hidden_states, self.in_proj)                                  # (B, L, 2*Di) token-major
         fwd = lambda t, perm: mamba_inner_tok(t, self.conv1d.weight, self.conv1d.bias, self.x_proj.weight,
                                                self.dt_proj.weight, A, Dp, dtb,
                                                perm=perm, out_rows=self._out_rows if perm is self._perm else None,
                                                delta_softplus=True)
-        st = self.scan_type
         if st == "v1":
             y = fwd(xz, None)
         elif st == "v2":

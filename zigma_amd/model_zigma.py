@@ -94,7 +94,8 @@ class PatchEmbed(nn.Module):
         bf16 inference path is ONE kernel (zigma_patch_embed_fwd) instead of unfold + K = C p^2 GEMM + bias + add"""
         Bsz, Cin, H, W = x.shape
         p = self.patch_size[0]
-        no_grad = not (torch.is_grad_enabled() and (x.requires_grad or self.proj.weight.requires_grad or (pos is not None and pos.requires_grad)))
+        no_grad = not (torch.is_grad_enabled() and (x.requires_grad or self.proj.weight.requires_grad
+                                                    or (self.proj.bias is not None and self.proj.bias.requires_grad) or (pos is not None and pos.requires_grad)))
         if no_grad and _embed.patch_embed_eligible(x, self.proj.weight, self.proj.bias, pos):
             return _embed.patch_embed(x, self.proj.weight, self.proj.bias, pos)
         cols = x.reshape(Bsz, Cin, H // p, p, W // p, p).permute(0, 2, 4, 1, 3, 5).reshape(Bsz, -1, Cin * p * p)

@@ -32,7 +32,12 @@ def wgrad(dy2, x2):
         return dy2.t() @ x2
     dy3 = dy2.reshape(s, m // s, n)
     x3 = x2.reshape(s, m // s, k)
-    return torch.bmm(dy3.transpose(1, 2), x3).sum(0, dtype=torch.float32).to(dy2.dtype)
+    # fp32 slab partials (one rounding at the end, like the single GEMM of the reference; a 16-bit partial could also overflow in fp16)
+    try:
+        part = torch.bmm(dy3.transpose(1, 2), x3, out_dtype=torch.float32)
+    except (TypeError, RuntimeError):      # (a torch without out_dtype on bmm)
+        part = torch.bmm(dy3.transpose(1, 2), x3).float()
+    return part.sum(0).to(dy2.dtype)
 
 
 class LinearTrainFn(torch.autograd.Function):
