@@ -27,15 +27,14 @@
 extern "C" {
 #endif
 
-#define ZIGMA_ABI_VERSION 9   /* 2: parameter blocks grew (row tables in the backward, checkpoints, reset_period)
+#define ZIGMA_ABI_VERSION 8   /* 2: parameter blocks grew (row tables in the backward, checkpoints, reset_period)
                                * 3: scan block: `info` out-field, ZIGMA_SCAN_Z_PREACTIVATED flag; zigma_linear_fwd
                                * 4: zigma_linear_params_t grew (gated residual epilogue); zigma_conv_x_proj_fwd, zigma_q_attn_fwd
                                * 5: pruned — zigma_q_attn_fwd and the dt product of zigma_conv_xproj_params_t removed (measured no faster,
                                *    archived under tools/experiments/)
                                * 6: zigma_cross_attn_bwd / zigma_cross_attn_bwd_chunks added
                                * 7: reset_period in the two backward blocks (zigma_scan_bwd_params_t reuses its padding, zigma_conv_bwd_params_t grew)
-                               * 8: zigma_patch_embed_fwd, zigma_timestep_embed_fwd, zigma_final_layer_fwd, zigma_skinny_linear_fwd added
-                               * 9: zigma_in_conv_x_proj_fwd (+ _workspace_bytes): the x half of in_proj inside the conv + x_proj kernel */
+                               * 8: zigma_patch_embed_fwd, zigma_timestep_embed_fwd, zigma_final_layer_fwd, zigma_skinny_linear_fwd added */
 
 /* zigma_scan_params_t.flags */
 #define ZIGMA_SCAN_Z_PREACTIVATED 2   /* z already holds silu(z) (the in_proj GEMM epilogue applied it): out_z = y * z */
@@ -468,42 +467,6 @@ typedef struct zigma_conv_xproj_params {
 } zigma_conv_xproj_params_t;
 
 int zigma_conv_x_proj_fwd(const zigma_conv_xproj_params_t *p, void *stream);
-
-/* ------------------------------------------------------------------------------------------
- * in_conv_x_proj (ABI 9): the x-HALF of Mamba.in_proj, the gather, the conv, SiLU and x_proj in one kernel — the x half of `xz`
- * never reaches memory:
- *   x[b, t, c]      = bf16( sum_e h[b, t, e] * w_in[c, e] )                                   c < dim   (rows 0..dim-1 of in_proj.weight)
- *   u[b, k, c]      = silu(conv_bias[c] + sum_{w<4} conv_weight[c, w] * x[b, x_row_index[k - 3 + w], c])     (x[<0] = 0)
- *   out[b*L + k, n] = sum_c u[b, k, c] * w[n, c]
- * Replaces the first `dim` output columns of F.linear(hidden_states, in_proj.weight) (reference mamba_simple.py:290-294), the
- * gather xz[:, :, perm] (mamba_simple.py:362-370), causal_conv1d_fn(..., activation="silu") and F.linear(conv1d_out,
- * x_proj_weight) (selective_scan_interface.py:307-322).  The z half of in_proj stays a projection of its own (zigma_linear_fwd
- * on rows dim..2*dim-1 of the weight).  Against in_proj + zigma_conv_x_proj_fwd this saves the write and the re-read of x:
- * 2 * 2 * batch * seqlen * dim bytes.  x is rounded to bf16 before the conv (it is a bf16 tensor in the reference), u before x_proj.
- * h: (batch, seqlen, k) rows, token order; w_in: (dim, k) rows; conv_weight: (dim, 4) contiguous; conv_bias: (dim);
- * w: (n, dim) rows; u: (batch, seqlen, dim) in SCAN order; out: (batch * seqlen, n) rows.
- * A workgroup walks `tiles` consecutive tiles of 128 scan positions; the three x rows in front of its first tile come from a small
- * pre-pass (second kernel of the same call) through `workspace` (zigma_in_conv_x_proj_fwd_workspace_bytes()).
- * Limits: bf16; k % 128 == 0 and k <= 768; dim % 64 == 0 and dim <= 1536; seqlen % 128 == 0; n <= 96, n % 8 == 0; 16-byte aligned rows.
- * flags: 0; timing probes (results wrong): 2 = no x product, 4 = no u stores, 8 = no conv arithmetic, 16 = no W_in stream, 32 = no fragment reads.
- * ------------------------------------------------------------------------------------------ */
-typedef struct zigma_in_conv_xproj_params {
-    int32_t batch, seqlen, dim, n, k;
-    int32_t dtype;           /* ZIGMA_BF16 */
-    int32_t flags;
-    int32_t pad_;
-    int64_t h_batch_stride, h_l_stride;
-    int64_t u_batch_stride, u_l_stride;
-    int64_t win_row_stride, w_row_stride, out_row_stride;
-    const void *h, *w_in, *conv_weight, *conv_bias, *w;
-    void *u, *out;
-    const int32_t *x_row_index;   /* or NULL */
-    void *workspace;
-    int64_t workspace_bytes;
-} zigma_in_conv_xproj_params_t;
-
-int zigma_in_conv_x_proj_fwd(const zigma_in_conv_xproj_params_t *p, void *stream);
-int64_t zigma_in_conv_x_proj_fwd_workspace_bytes(const zigma_in_conv_xproj_params_t *p);
 
 /* ------------------------------------------------------------------------------------------
  * Dense projection on the matrix cores:  out = x @ w^T (+ bias) (+ SiLU on a column range), bf16 in / fp32 accumulate / bf16 out.

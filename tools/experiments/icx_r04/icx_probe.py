@@ -31,7 +31,7 @@ def main():
     out = {}
     dev = torch.device("cuda:0")
     torch.manual_seed(0)
-    shapes = ((64, 1024, 640, 1280, 72, "zigzag"), (4, 16384, 640, 1280, 72, "zigzag"), (32, 1024, 768, 1536, 80, "none"))
+    shapes = ((64, 1024, 640, 1280, 72, "zigzag"), (4, 16384, 640, 1280, 72, "zigzag"), (32, 1024, 640, 1280, 80, "none"))
     if os.environ.get("ONE") == "1":
         shapes = shapes[:1]
     for (B, L, E, Di, n, tab) in shapes:
@@ -73,8 +73,8 @@ def main():
             for fl in (2, 4, 8, 12, 16, 30, 32, 62):
                 out[key][f"probe_{fl}_us"] = timeit(lambda: in_conv_x_proj(h, w_in[:Di], conv_w, conv_b, w_x, perm, _flags=fl))
         print(key, json.dumps(out[key]), flush=True)
-    os.makedirs("gpurun_out", exist_ok=True)
-    json.dump(out, open("gpurun_out/icx_probe.json", "w"), indent=1)
+        os.makedirs("gpurun_out", exist_ok=True)
+        json.dump(out, open("gpurun_out/icx_probe.json", "w"), indent=1)
 
 
 if __name__ == "__main__":

@@ -155,21 +155,13 @@ class ConvXProjParams(C.Structure):
                 + [(n, vp) for n in ("x", "conv_weight", "conv_bias", "w", "u", "out", "x_row_index")])
 
 
-class InConvXProjParams(C.Structure):
-    _fields_ = ([(n, i32) for n in ("batch", "seqlen", "dim", "n", "k", "dtype", "flags", "pad_")]
-                + [(n, i64) for n in ("h_batch_stride", "h_l_stride", "u_batch_stride", "u_l_stride", "win_row_stride", "w_row_stride",
-                                      "out_row_stride")]
-                + [(n, vp) for n in ("h", "w_in", "conv_weight", "conv_bias", "w", "u", "out", "x_row_index", "workspace")]
-                + [("workspace_bytes", i64)])
-
-
 class LinearParams(C.Structure):
     _fields_ = ([("m", i64), ("n", i32), ("k", i32), ("dtype", i32), ("flags", i32), ("silu_from_col", i32), ("pad_", i32)]
                 + [(n, i64) for n in ("x_row_stride", "w_row_stride", "out_row_stride")] + [(n, vp) for n in ("x", "w", "bias", "out")]
                 + [("residual", vp), ("gate", vp), ("res_row_stride", i64), ("gate_batch_stride", i64), ("rows_per_batch", i32), ("pad2_", i32)])
 
 
-EXPORTS = ("zigma_linear_fwd", "zigma_conv_x_proj_fwd", "zigma_in_conv_x_proj_fwd", "zigma_in_conv_x_proj_fwd_workspace_bytes", "zigma_scale_reduce_bwd", "zigma_selective_scan_fwd", "zigma_causal_conv1d_fwd", "zigma_add_norm_fwd", "zigma_dt_proj_softplus_fwd", "zigma_cross_attn_fwd", "zigma_x_proj_fwd", "zigma_selective_scan_bwd",
+EXPORTS = ("zigma_linear_fwd", "zigma_conv_x_proj_fwd", "zigma_scale_reduce_bwd", "zigma_selective_scan_fwd", "zigma_causal_conv1d_fwd", "zigma_add_norm_fwd", "zigma_dt_proj_softplus_fwd", "zigma_cross_attn_fwd", "zigma_x_proj_fwd", "zigma_selective_scan_bwd",
            "zigma_selective_scan_bwd_workspace_bytes", "zigma_causal_conv1d_bwd",
            "zigma_causal_conv1d_bwd_workspace_bytes", "zigma_add_norm_bwd", "zigma_add_norm_bwd_workspace_bytes",
            "zigma_strerror",
@@ -193,15 +185,13 @@ def lib():
                          ("zigma_selective_scan_bwd", ScanBwdParams), ("zigma_causal_conv1d_bwd", ConvBwdParams),
                          ("zigma_add_norm_bwd", NormBwdParams), ("zigma_cross_attn_fwd", XAttnParams), ("zigma_cross_attn_bwd", XAttnBwdParams), ("zigma_patch_embed_fwd", PatchEmbedParams),
                          ("zigma_timestep_embed_fwd", TimestepEmbedParams), ("zigma_final_layer_fwd", FinalLayerParams), ("zigma_skinny_linear_fwd", SkinnyParams), ("zigma_x_proj_fwd", XProjParams),
-                         ("zigma_linear_fwd", LinearParams), ("zigma_conv_x_proj_fwd", ConvXProjParams), ("zigma_in_conv_x_proj_fwd", InConvXProjParams),
-                         ("zigma_scale_reduce_bwd", GlueBwdParams)):
+                         ("zigma_linear_fwd", LinearParams), ("zigma_conv_x_proj_fwd", ConvXProjParams), ("zigma_scale_reduce_bwd", GlueBwdParams)):
             fn = getattr(L, name)
             fn.argtypes = [C.POINTER(st), vp]
             fn.restype = C.c_int
         for name, st in (("zigma_selective_scan_bwd_workspace_bytes", ScanBwdParams),
                          ("zigma_causal_conv1d_bwd_workspace_bytes", ConvBwdParams),
-                         ("zigma_add_norm_bwd_workspace_bytes", NormBwdParams),
-                         ("zigma_in_conv_x_proj_fwd_workspace_bytes", InConvXProjParams)):
+                         ("zigma_add_norm_bwd_workspace_bytes", NormBwdParams)):
             fn = getattr(L, name)
             fn.argtypes = [C.POINTER(st)]
             fn.restype = C.c_int64
@@ -211,7 +201,7 @@ def lib():
         L.zigma_strerror.restype = C.c_char_p
         L.zigma_abi_version.restype = C.c_int
         L.zigma_last_kernel.restype = C.c_char_p
-        if L.zigma_abi_version() != 9:
+        if L.zigma_abi_version() != 8:
             raise RuntimeError("zigma_amd: libzigma_hip.so ABI version mismatch")
         _lib = L
     return _lib

@@ -9,16 +9,21 @@ row-index table consumed by the conv and scan kernels, so no `index_select`, `fl
 `rearrange(...).contiguous()` pass exists (reference :362-370, :320-337, :388-394).
 """
 import math
+import os
 
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
 from .linear import gated_residual_eligible, linear, linear_eligible
-from .selective_scan_interface import mamba_inner_hidden, mamba_inner_hidden_eligible, mamba_inner_tok
+from .selective_scan_interface import mamba_inner_tok
 from .wgrad import linear_train
 
 NO_COPY_TEMPORAL = True      # video "t" layers on strided views (False: the transposing-copy form; A/B in the tests)
+
+
+IN_PROJ_SPLIT = os.environ.get("ZIGMA_IN_PROJ_SPLIT", "1") == "1"      # in_proj as two half-width launches of the own kernel
+IN_PROJ_SPLIT_MIN_TOKENS = 32768
 
 
 def _int32_table(t, device):
@@ -205,14 +210,6 @@ class Mamba(nn.Module):
         batch, seqlen, _ = hidden_states.shape
         A, Dp, dtb = self._scan_consts("")
         st = self.scan_type
-        if self.in_proj.bias is None and (st == "v1" or (st.startswith(("zigzagN", "hilbertN", "randomN")) and not self.extras)):
-            # single-sweep layers at inference: `xz` is never formed — the x half of in_proj runs inside the conv + x_proj kernel
-            # (zigma_in_conv_x_proj_fwd), the z half is a projection of its own
-            perm = None if st == "v1" else self._perm
-            if mamba_inner_hidden_eligible(hidden_states, self.in_proj.weight, self.conv1d.weight, self.conv1d.bias, self.x_proj.weight, perm):
-                return mamba_inner_hidden(hidden_states, self.in_proj.weight, self.conv1d.weight, self.conv1d.bias, self.x_proj.weight,
-                                          self.dt_proj.weight, A, Dp, dtb, perm=perm,
-                                          out_rows=self._out_rows if perm is not None else None, delta_softplus=True)
         xz = self._proj(hidden_states, self.in_proj)                                  # (B, L, 2*Di) token-major
         fwd = lambda t, perm: mamba_inner_tok(t, self.conv1d.weight, self.conv1d.bias, self.x_proj.weight,
                                                self.dt_proj.weight, A, Dp, dtb,
@@ -270,4 +267,15 @@ class Mamba(nn.Module):
         """in_proj / out_proj: the hand-written MFMA kernel where it applies (zigma_amd.linear), the library otherwise"""
         if linear_eligible(x, lin.weight, lin.bias):
             return linear(x, lin.weight, lin.bias)
+        n = lin.weight.shape[0]
+        if (IN_PROJ_SPLIT and lin.bias is None and n % 512 == 0 and n >= 2048 and x.dim() == 3
+                and linear_eligible(x, lin.weight[:n // 2], None, prefer_own=True) and x.shape[0] * x.shape[1] >= IN_PROJ_SPLIT_MIN_TOKENS):
+            # in_proj as TWO launches of the own 4-wave kernel, one per half of the output columns, into one (B, L, 2 d_inner) buffer:
+            # a half's weight panel (1.6 MB) stays in an XCD's L2 beside the activation panels, which the whole panel (3.3 MB) does
+            # not — 2 x ~100 us against 215-222 us for the same kernel on all 2560 columns and 190-200 us for hipBLASLt
+            out = torch.empty(*x.shape[:-1], n, device=x.device, dtype=x.dtype)
+            o2 = out.view(-1, n)
+            linear(x, lin.weight[:n // 2], out=o2[:, :n // 2])
+            linear(x, lin.weight[n // 2:], out=o2[:, n // 2:])
+            return out
         return linear_train(x, lin.weight, lin.bias)       # (F.linear; under autograd with the slab-wise weight gradient, zigma_amd/wgrad.py)
