@@ -17,12 +17,16 @@ roofline  : the fused zigzag selective-scan kernel, timed with HIP events around
             `frac` is the HBM-roofline fraction the metric asks for; the kernel itself is VALU-issue limited
             (DESIGN.md §3.1), so the line also carries `valu_frac` = the recurrence's VALU floor at the guide's issue
             rates (4 plain ops x 2 cycles + 1 v_exp_f32 x 8 cycles per (element, state) wave-instruction group)
-            divided by the measured launch time.  `traffic` is NOT measured in this run: it is the per-launch HBM
-            byte count of the committed rocprofv3 PMC passes and is labelled with the file it came from.
+            divided by the measured launch time.  `traffic`: HBM bytes per launch from two rocprofv3 PMC passes (FETCH_SIZE doubled,
+            WRITE_SIZE — MI355X_MICROARCH.md) of the same kernel launch as the model makes it, run as child processes AFTER the
+            timed region when `rocprofv3` is on the box (`traffic_source: "measured ..."`); otherwise the byte count of the
+            committed passes, labelled with the file it came from.
 cpu_baseline : on the host cores, bounded sample (forwards of the same model at B=2), rank 0, N=1 only.  Where
             /root/reference is mounted (the build container) the reference's OWN CPU path — its unmodified `ZigMa.forward`
             over `selective_scan_ref` / `causal_conv1d_ref` through oracle/ref_shim.py, `kind: "reference"`; on the GPU box
-            (a Python reference cannot travel) the numpy oracle's forward of the same architecture, `kind: "port"`.
+            (a Python reference cannot travel) the torch-CPU restatement of the SAME ATen formulation (oracle/torch_port.py:
+            materialised (B, D, L, N) einsum tensors, per-step loop, torch's CPU thread pool; pinned to the reference's golden
+            outputs), `kind: "port-torch"`, `threads` = torch threads used.  (The numpy oracle, `kind: "port"`, is the last resort.)
 check       : one forward OUTSIDE the timed region compared with the same model run through the unfused composition
             (library projections, no epilogue fusion, the two-kernel conv / x_proj): finite + norm-wise distance.
 N > 1 without a launcher: `python bench.py --gpus N` re-executes itself under torch.distributed.run with N ranks.
@@ -74,6 +78,41 @@ class ScanTimer:
 
     def mean_ms(self):
         return sum(a.elapsed_time(b) for a, b in self.pairs) / max(len(self.pairs), 1)
+
+
+def pmc_traffic_live(limit_s=150):
+    """HBM bytes per scan launch measured NOW: two rocprofv3 --pmc passes (FETCH_SIZE; WRITE_SIZE — they do not fit one pass) over
+    tools/scan_one.py (the scan exactly as the model launches it at the headline shape), FETCH_SIZE doubled as
+    MI355X_MICROARCH.md prescribes for gfx950.  Child processes with a hard time limit; None when rocprofv3 is missing or fails."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    exe = shutil.which("rocprofv3")
+    if exe is None or os.environ.get("ZIGMA_BENCH_PMC", "1") == "0":
+        return None, None
+    vals = {}
+    t_end = time.time() + limit_s
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        d = tempfile.mkdtemp(prefix="zigma_pmc_")
+        try:
+            subprocess.run([exe, "--pmc", counter, "--output-format", "csv", "-d", d, "-o", "pmc", "--", sys.executable,
+                            os.path.join(ROOT, "tools", "scan_one.py")], capture_output=True, text=True,
+                           timeout=max(10, t_end - time.time()), cwd=d, env=dict(os.environ, TMPDIR=d, N="8"))
+            got = []
+            for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+                for r in csv.DictReader(open(f)):
+                    if "scan_tok" in r["Kernel_Name"] and r["Counter_Name"] == counter:
+                        got.append(float(r["Counter_Value"]))
+            if not got:
+                return None, None
+            vals[counter] = sum(got) / len(got)
+        except Exception:
+            return None, None
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
+    return int(2 * vals["FETCH_SIZE"] * 1024 + vals["WRITE_SIZE"] * 1024), "measured: rocprofv3 --pmc FETCH_SIZE (x2) / WRITE_SIZE over tools/scan_one.py"
 
 
 def pmc_traffic():
@@ -202,6 +241,53 @@ def cpu_baseline_reference(wl, seed=0, budget_s=20.0):
                                         shape=f"B={B}, Di={Di}, L={L}, N={N}, fp32"))
 
 
+def cpu_baseline_port_torch(wl, seed=0, budget_s=20.0):
+    """The reference's CPU arithmetic where the reference itself is not mounted: oracle/torch_port.py (the same ATen ops and the
+    same torch thread pool as selective_scan_ref / mamba_inner_ref / the model's forward), README model, B=2, fp32."""
+    import numpy as np
+    from oracle import torch_port as tp
+    threads = min(_host_threads(), 32)
+    torch.set_num_threads(threads)
+    from zigma_amd.model_zigma import ZigMa
+    torch.manual_seed(seed)
+    m = ZigMa(device="cpu", dtype=torch.float32, **wl["model"])
+    state = {k: v.detach().numpy() for k, v in m.state_dict().items()}
+    rng = np.random.default_rng(seed)
+    for k in state:                     # non-zero gates, as on the GPU side
+        if "adaLN_modulation.1.bias" in k:
+            state[k] = (rng.standard_normal(state[k].shape) * 0.5).astype(np.float32)
+    pm = tp.ZigMaTorchPort(state, wl["model"])
+    B = 2
+    L = (wl["model"]["img_dim"] // wl["model"]["patch_size"]) ** 2
+    x = rng.standard_normal((B,) + wl["x"]).astype(np.float32)
+    t = rng.random(B).astype(np.float32)
+    y = rng.random((B,) + wl["y"][1:]).astype(np.float32)
+    n, t0 = 0, time.perf_counter()
+    with torch.no_grad():
+        while n == 0 or (time.perf_counter() - t0) * (n + 1) / n < budget_s:
+            pm.forward(x, t, y)
+            n += 1
+    dt = (time.perf_counter() - t0) / n
+    g = torch.Generator().manual_seed(seed)
+    Di, N = 2 * wl["model"]["embed_dim"], 16
+    u, dl, z = (torch.randn(B, Di, L, generator=g) for _ in range(3))
+    A = -torch.rand(Di, N, generator=g)
+    Bm, Cm = torch.randn(B, N, L, generator=g), torch.randn(B, N, L, generator=g)
+    D, db = torch.randn(Di, generator=g), torch.rand(Di, generator=g)
+    with torch.no_grad():
+        tp.selective_scan_ref(u, dl, A, Bm, Cm, D, z, db, True)
+        s0 = time.perf_counter()
+        tp.selective_scan_ref(u, dl, A, Bm, Cm, D, z, db, True)
+        sdt = time.perf_counter() - s0
+    scan_bytes = B * L * (4 * 4 * Di + 2 * 4 * N) + 4 * Di * (N + 2)          # fp32 I/O
+    return dict(value=B * L / dt, unit="tokens/s", cores=threads, threads=threads, kind="port-torch", cpu=_cpu_model(),
+                sample=f"{n} forward(s) of the same model (E=640, depth=18, has_text) at B={B}, fp32, oracle/torch_port.py = the "
+                       f"reference's ATen formulation (selective_scan_ref's einsum tensors + per-step loop), torch "
+                       f"{torch.__version__.split('+')[0]} CPU, {threads} threads, {dt:.1f} s per forward",
+                selective_scan_ref=dict(tokens_per_s=B * L / sdt, GBps=scan_bytes / sdt / 1e9, seconds=sdt,
+                                        shape=f"B={B}, Di={Di}, L={L}, N={N}, fp32"))
+
+
 def cpu_baseline_port(wl, seed=0):
     """Fallback: the numpy oracle's forward of the same architecture at B=2 (only when the reference is not importable)."""
     import numpy as np
@@ -229,8 +315,9 @@ def cpu_baseline_port(wl, seed=0):
     om.forward(x, t, y)
     dt = time.perf_counter() - t0
     L = (wl["model"]["img_dim"] // wl["model"]["patch_size"]) ** 2
-    return dict(value=B * L / dt, unit="tokens/s", cores=threads, kind="port", cpu=_cpu_model(),
-                sample=f"1 forward of the same model (E=640, depth=18, has_text) at B={B}, fp32 numpy oracle, {dt:.1f} s")
+    return dict(value=B * L / dt, unit="tokens/s", cores=1, threads_recurrence=1, threads_blas=threads, kind="port", cpu=_cpu_model(),
+                sample=f"1 forward of the same model (E=640, depth=18, has_text) at B={B}, fp32 numpy oracle (recurrence on ONE "
+                       f"thread, the GEMMs on {threads} BLAS threads), {dt:.1f} s")
 
 
 def cpu_baseline(wl, name, limit_s=240):
@@ -238,7 +325,7 @@ def cpu_baseline(wl, name, limit_s=240):
     path crawl; the GPU numbers of the line must not depend on it)."""
     import subprocess
     from oracle import ref_shim
-    for kind in (["reference"] if ref_shim.available() else []) + ["port"]:
+    for kind in (["reference"] if ref_shim.available() else []) + ["port-torch", "port"]:
         try:
             r = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-baseline-only", kind, "--workload", name],
                                capture_output=True, text=True, timeout=limit_s,
@@ -281,7 +368,7 @@ def main():
     ap.add_argument("--cpu-baseline-only", default=None, help=argparse.SUPPRESS)      # child-process leg of cpu_baseline()
     args = ap.parse_args()
     if args.cpu_baseline_only:
-        fn = cpu_baseline_reference if args.cpu_baseline_only == "reference" else cpu_baseline_port
+        fn = {"reference": cpu_baseline_reference, "port-torch": cpu_baseline_port_torch}.get(args.cpu_baseline_only, cpu_baseline_port)
         print(json.dumps(fn(WORKLOADS[args.workload])), flush=True)
         return
 
@@ -332,7 +419,9 @@ def main():
         if timer.pairs:
             ms = timer.mean_ms()
             ach = algo_bytes / (ms * 1e-3)
-            traffic, traffic_src = pmc_traffic()
+            traffic, traffic_src = (None, None) if args.no_cpu_baseline else pmc_traffic_live()      # (both are the slow, untimed legs)
+            if traffic is None:
+                traffic, traffic_src = pmc_traffic()
             # VALU floor of the recurrence at the guide's issue rates (MI355X_MICROARCH.md: v_fma_f32 2 cycles per wave64
             # instruction per SIMD, transcendental quarter rate = 8): 4 plain + 1 exp per (element, state), 1024 SIMDs
             groups = batch * L * Di * N / 64
@@ -346,7 +435,8 @@ def main():
                         traffic_source=traffic_src, launch_us=ms * 1e3, launches=len(timer.pairs),
                         algorithmic_bytes=algo_bytes, limiter="valu", valu_floor_us=valu_floor_us,
                         valu_frac=valu_floor_us / (ms * 1e3), valu_floor_measured_rates_us=valu_floor_measured_us,
-                        valu_frac_measured_rates=valu_floor_measured_us / (ms * 1e3))
+                        valu_frac_measured_rates=valu_floor_measured_us / (ms * 1e3),
+                        valu_rates_source="profiles/r02_ubench2_valu_rates.txt (tools/ubench2: ns per wave-instruction per SIMD)")
         line = dict(metric="denoiser-forward latents/sec (BxL tokens/s), ZigMa d=640 L=32^2",
                     value=world * batch * L * args.steps / elapsed, unit="tokens/s", n_gpus=world, steps=args.steps,
                     warmup=args.warmup, ms_per_step=elapsed / args.steps * 1e3, higher_is_better=True, scaling="weak",

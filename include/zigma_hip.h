@@ -27,14 +27,15 @@
 extern "C" {
 #endif
 
-#define ZIGMA_ABI_VERSION 8   /* 2: parameter blocks grew (row tables in the backward, checkpoints, reset_period)
+#define ZIGMA_ABI_VERSION 9   /* 2: parameter blocks grew (row tables in the backward, checkpoints, reset_period)
                                * 3: scan block: `info` out-field, ZIGMA_SCAN_Z_PREACTIVATED flag; zigma_linear_fwd
                                * 4: zigma_linear_params_t grew (gated residual epilogue); zigma_conv_x_proj_fwd, zigma_q_attn_fwd
                                * 5: pruned — zigma_q_attn_fwd and the dt product of zigma_conv_xproj_params_t removed (measured no faster,
                                *    archived under tools/experiments/)
                                * 6: zigma_cross_attn_bwd / zigma_cross_attn_bwd_chunks added
                                * 7: reset_period in the two backward blocks (zigma_scan_bwd_params_t reuses its padding, zigma_conv_bwd_params_t grew)
-                               * 8: zigma_patch_embed_fwd, zigma_timestep_embed_fwd, zigma_final_layer_fwd, zigma_skinny_linear_fwd added */
+                               * 8: zigma_patch_embed_fwd, zigma_timestep_embed_fwd, zigma_final_layer_fwd, zigma_skinny_linear_fwd added
+                               * 9: zigma_scan_params_t grew: dt_x / dt_w (dt_proj + softplus inside the scan kernel) */
 
 /* zigma_scan_params_t.flags */
 #define ZIGMA_SCAN_Z_PREACTIVATED 2   /* z already holds silu(z) (the in_proj GEMM epilogue applied it): out_z = y * z */
@@ -120,6 +121,15 @@ typedef struct zigma_scan_params {
     /* optional HOST pointer to int32[2], written by the call before it returns (never by a kernel):
      * info[0] = ZIGMA_SCAN_KERNEL_* that was launched, info[1] = 1 iff `checkpoints` is being written. */
     int32_t *info;
+    /* ABI 9 — dt_proj INSIDE the scan (token-major hot kernel, bf16, whole-sequence mode only): when dt_x != NULL, `delta` is ignored and
+     *   delta'[b, l, d] = softplus( sum_{r < dt_rank} dt_x[b, l, r] * dt_w[d, r] + delta_bias[d] )
+     * is formed by the workgroup itself (v_mfma_f32_16x16x32_bf16 in the tile prologue) from the dt columns of the x_dbl rows it
+     * already fetches B_l / C_l from — the (batch, seqlen, dim) delta tensor (reference selective_scan_interface.py:323) is
+     * neither written nor read.  dt_x: rows of scan position l (row pitch dt_x_l_stride, 16-byte aligned), dt_w: (dim, dt_rank)
+     * rows of pitch dt_w_row_stride; dt_rank % 4 == 0, <= 48.  delta_softplus must be 1. */
+    const void *dt_x, *dt_w;
+    int64_t dt_x_batch_stride, dt_x_l_stride, dt_w_row_stride;
+    int32_t dt_rank, pad3_;
 } zigma_scan_params_t;
 
 int zigma_selective_scan_fwd(const zigma_scan_params_t *p, void *stream);

@@ -152,6 +152,49 @@ def test_bench_block_path_vs_reference(variant, monkeypatch):
     assert e_fp32 < 1.1 * ref_noise, (e_fp32, ref_noise)
 
 
+def test_no_text_block_path_trace_and_oracle(monkeypatch):
+    """Blocks WITHOUT the attention branch (BASELINE config 3: unconditional, in_channels 4) at 16 384 tokens: out_proj carries the
+    block's gated add in its epilogue (model_zigma.FUSE_OUT_PROJ_ADD_NO_TEXT; reference Block.forward model_zigma.py:416-440) —
+    asserted from the call trace —, and the output agrees with the unfused composition and, on the first and last sample, with
+    the fp32 numpy oracle of the same weights."""
+    import zigma_amd.model_zigma as mz
+    from zigma_amd import _lib
+    from zigma_amd.model_zigma import ZigMa
+    cfg = dict(in_channels=4, img_dim=32, embed_dim=640, depth=4, patch_size=1, scan_type="zigzagN8", use_pe=2)
+    m = ZigMa(device="cpu", dtype=torch.bfloat16, **cfg)
+    fill_state(m, 1234)
+    state = {k: v.detach().float().numpy() for k, v in m.state_dict().items()}
+    m = m.to(DEV).eval()
+    Bsz = 16
+    gen = torch.Generator().manual_seed(5)
+    x, t = torch.randn(Bsz, 4, 32, 32, generator=gen), torch.rand(Bsz, generator=gen)
+    xb, tb = x.to(DEV).bfloat16(), t.to(DEV).bfloat16()
+    trace = []
+    monkeypatch.setattr(_lib, "TRACE", trace)
+    with torch.no_grad():
+        out = m(xb, tb, None)
+    monkeypatch.setattr(_lib, "TRACE", None)
+    counts, gated = _trace_counts(trace)
+    assert gated == cfg["depth"], (gated, counts)                     # out_proj + gated add, every block
+    assert counts.get(("zigma_conv_x_proj_fwd", "conv_x_proj_mfma"), 0) == cfg["depth"], counts
+    assert sum(c for (fn, k), c in counts.items() if fn == "zigma_selective_scan_fwd" and k.startswith("scan_tok2")) == cfg["depth"], counts
+    monkeypatch.setattr(mz, "FUSE_OUT_PROJ_ADD_NO_TEXT", False)
+    trace2 = []
+    monkeypatch.setattr(_lib, "TRACE", trace2)
+    with torch.no_grad():
+        out_u = m(xb, tb, None)
+    monkeypatch.setattr(_lib, "TRACE", None)
+    assert _trace_counts(trace2)[1] == 0
+    e_fu = rel_err(N(out), N(out_u))
+    om = zo.ZigMaOracle(state, cfg)
+    rows = [0, Bsz - 1]
+    ref = om.forward(N(xb.float())[rows], N(tb.float())[rows], None)
+    e_or, e_or_u = rel_err(N(out)[rows], ref), rel_err(N(out_u)[rows], ref)
+    print(f"no-text blocks, B={Bsz}: fused vs unfused {e_fu:.3e}; vs fp32 oracle: fused {e_or:.3e}, unfused {e_or_u:.3e}")
+    assert np.isfinite(N(out)).all() and e_fu < 1e-2, e_fu
+    assert e_or < 3e-2 and e_or < 1.25 * e_or_u + 2e-3, (e_or, e_or_u)
+
+
 # ---------------------------------------------------------------------------------------------------
 # Mamba inner at full size, bf16, real zigzag tables
 # ---------------------------------------------------------------------------------------------------

@@ -438,6 +438,73 @@ def test_dt_proj_softplus_mfma_vs_oracle(M, Di, R, S):
     assert rel_err(N(lin), zo.bf16_round(x[:, :, :R] @ w.T)) < 1e-3
 
 
+@pytest.mark.parametrize("Bsz,L,Di,R,use_perm", [(2, 64, 128, 40, False), (3, 1024, 192, 40, True), (2, 256, 64, 48, True),
+                                                 (5, 48, 1280, 40, True), (1, 16, 64, 32, False)])
+def test_scan_tok2_dt_proj_in_kernel_vs_oracle(Bsz, L, Di, R, use_perm):
+    """ABI 9: dt_proj + bias + softplus inside scan_tok2_kernel (zigma_scan_params_t.dt_x / dt_w) against the numpy oracle's scan on
+    delta' = x_dbl[:, :, :R] @ W_dt^T (reference selective_scan_interface.py:323 + softplus(delta + bias) of its kernel) evaluated in
+    fp32 on the same bf16 operands, and against the two-kernel path (dt_proj_softplus_kernel + scan) whose delta is a bf16 tensor."""
+    from zigma_amd import _lib
+    from zigma_amd.selective_scan_interface import dt_in_scan_eligible, dt_proj_softplus, scan_raw
+    Nst = 16
+    rng = np.random.default_rng(Bsz * 1000 + L + R)
+    u = bf(rng.standard_normal((Bsz, L, Di)).astype(np.float32))
+    z = bf(rng.standard_normal((Bsz, L, Di)).astype(np.float32))
+    xd = bf(rng.standard_normal((Bsz, L, R + 2 * Nst)).astype(np.float32))
+    w = bf((rng.standard_normal((Di, R)) * R ** -0.5).astype(np.float32))
+    A = -np.exp(np.log(np.arange(1, Nst + 1, dtype=np.float32))[None].repeat(Di, 0) + 0.2 * rng.standard_normal((Di, Nst))).astype(np.float32)
+    D = (1 + 0.2 * rng.standard_normal(Di)).astype(np.float32)
+    db = (rng.standard_normal(Di) - 3.0).astype(np.float32)
+    db[0] = 26.0                                                  # softplus pass-through branch (> 20)
+    perm = np.random.default_rng(9).permutation(L).astype(np.int64) if use_perm else None
+    ut, zt, xt = T(u, torch.bfloat16), T(z, torch.bfloat16), T(xd, torch.bfloat16)
+    wt = T(w, torch.bfloat16)
+    pt = None if perm is None else torch.from_numpy(perm).to(DEV).to(torch.int32)
+    assert dt_in_scan_eligible(ut, xt, wt)
+    Bv, Cv = xt[:, :, R:R + Nst].transpose(1, 2).unsqueeze(1), xt[:, :, R + Nst:].transpose(1, 2).unsqueeze(1)
+    y = torch.empty(Bsz, L, Di, device=DEV, dtype=torch.bfloat16)
+    info = []
+    scan_raw(ut.transpose(1, 2), None, T(A), Bv, Cv, T(D), zt.transpose(1, 2), T(db), True, out_z=y.transpose(1, 2),
+             z_row_index=pt, out_row_index=pt, want_out=False, dt_x=xt, dt_w=wt, info=info)
+    assert _lib.last_kernel() == "scan_tok2_n16_dtproj" and info[0] == _lib.SCAN_KERNEL_TOK2
+    # oracle: scan position k reads z from row perm[k] and writes row perm[k]
+    delta = np.einsum("blr,dr->bdl", xd[:, :, :R].astype(np.float32), w.astype(np.float32))
+    zz = z if perm is None else z[:, perm]
+    ref = zo.selective_scan(u.transpose(0, 2, 1), delta, A, xd[:, :, R:R + Nst].transpose(0, 2, 1), xd[:, :, R + Nst:].transpose(0, 2, 1),
+                            D, zz.transpose(0, 2, 1), db, True).transpose(0, 2, 1)
+    got = N(y)
+    if perm is not None:
+        got = got[:, perm]
+    e = rel_err(got, bf(ref))
+    assert np.isfinite(got).all() and e < 1e-3, e
+    assert np.allclose(got, ref, rtol=3e-2, atol=5e-2)           # the reference's bf16 bounds (test_selective_scan.py:47)
+    # the path it replaces
+    dl = dt_proj_softplus(xt, R, wt, T(db), True)
+    y2 = torch.empty_like(y)
+    scan_raw(ut.transpose(1, 2), dl.transpose(1, 2), T(A), Bv, Cv, T(D), zt.transpose(1, 2), None, False, out_z=y2.transpose(1, 2),
+             z_row_index=pt, out_row_index=pt, want_out=False)
+    e2 = rel_err(N(y), N(y2))
+    print(f"in-kernel dt_proj B={Bsz} L={L} Di={Di} R={R}: vs oracle {e:.2e}; vs dt_proj kernel + scan (bf16 delta) {e2:.2e}")
+    assert e2 < 5e-3, e2
+
+
+def test_scan_dt_in_kernel_limits():
+    from zigma_amd.selective_scan_interface import scan_raw
+    Bsz, L, Di, R, Nst = 1, 32, 64, 40, 16
+    ut = torch.randn(Bsz, L, Di, device=DEV).bfloat16()
+    xt = torch.randn(Bsz, L, R + 2 * Nst, device=DEV).bfloat16()
+    wt = torch.randn(Di, R, device=DEV).bfloat16()
+    A = -torch.rand(Di, Nst, device=DEV)
+    Bv, Cv = xt[:, :, R:R + Nst].transpose(1, 2).unsqueeze(1), xt[:, :, R + Nst:].transpose(1, 2).unsqueeze(1)
+    with pytest.raises(RuntimeError):       # delta=None without the pair
+        scan_raw(ut.transpose(1, 2), None, A, Bv, Cv, None, ut.transpose(1, 2), None, True)
+    with pytest.raises(RuntimeError):       # fp16 operands: the in-kernel product is bf16 only
+        scan_raw(ut.half().transpose(1, 2), None, A, Bv.half(), Cv.half(), None, ut.half().transpose(1, 2), None, True,
+                 dt_x=xt.half(), dt_w=wt.half())
+    with pytest.raises(RuntimeError):       # dt_rank < 32
+        scan_raw(ut.transpose(1, 2), None, A, Bv, Cv, None, ut.transpose(1, 2), None, True, dt_x=xt, dt_w=wt[:, :16].contiguous())
+
+
 # ---------------------------------------------------------------------------------------------------
 # mamba inner + model
 # ---------------------------------------------------------------------------------------------------

@@ -33,7 +33,7 @@ def test_cabi_exports_every_declared_symbol(libpath):
         assert hasattr(L, name), name
     L.zigma_abi_version.restype = ctypes.c_int
     L.zigma_strerror.restype = ctypes.c_char_p
-    assert L.zigma_abi_version() == 8
+    assert L.zigma_abi_version() == 9
     assert L.zigma_strerror(-2) == b"size out of the supported range"
     from zigma_amd import _lib
     assert set(_lib.EXPORTS) <= declared

@@ -36,6 +36,8 @@ class ScanParams(C.Structure):
         + [(n, vp) for n in ("u", "delta", "A", "B", "C", "D", "delta_bias", "z", "out", "out_z", "x",
                              "z_row_index", "out_row_index", "checkpoints")]
         + [("reset_period", i32), ("pad2_", i32), ("info", C.POINTER(C.c_int32))]
+        + [("dt_x", vp), ("dt_w", vp), ("dt_x_batch_stride", i64), ("dt_x_l_stride", i64), ("dt_w_row_stride", i64),
+           ("dt_rank", i32), ("pad3_", i32)]
     )
 
 
@@ -201,7 +203,7 @@ def lib():
         L.zigma_strerror.restype = C.c_char_p
         L.zigma_abi_version.restype = C.c_int
         L.zigma_last_kernel.restype = C.c_char_p
-        if L.zigma_abi_version() != 8:
+        if L.zigma_abi_version() != 9:
             raise RuntimeError("zigma_amd: libzigma_hip.so ABI version mismatch")
         _lib = L
     return _lib

@@ -120,6 +120,7 @@ __global__ __launch_bounds__(64) void scan_generic_kernel(const zigma_scan_param
 
 // token-major kernel: scan_tok.inc, instantiated per I/O element type in scan_tok_{bf16,f16,f32}.hip
 int launch_scan_tok_bf16(const zigma_scan_params_t &p, hipStream_t stream);
+int launch_scan_tok_bf16_dtp(const zigma_scan_params_t &p, hipStream_t stream);
 int launch_scan_tok_f16(const zigma_scan_params_t &p, hipStream_t stream);
 int launch_scan_tok_f32(const zigma_scan_params_t &p, hipStream_t stream);
 
@@ -189,6 +190,14 @@ extern "C" int zigma_selective_scan_fwd(const zigma_scan_params_t *pp, void *str
 #endif
     if (p.flags & ~(ZIGMA_SCAN_Z_PREACTIVATED | ZIGMA_SCAN_PROBE_V1 | (1 << ZIGMA_SCAN_PROBE_PRIO_SHIFT) | kProbeBits)) return ZIGMA_ERR_UNSUPPORTED;
     if (p.batch == 0 || p.dim == 0 || p.seqlen == 0) return ZIGMA_OK;  // empty (pointers may be NULL): nothing to launch
+    if (p.dt_x) {       // ABI 9: dt_proj inside the token-major hot kernel; `delta` is not read (the layout checks below see u's strides)
+        if (!p.u || !p.dt_w || !p.A || !p.B || !p.C || !p.z || !p.out_z) return ZIGMA_ERR_NULL;
+        zigma_scan_params_t q = p;
+        q.delta = p.u;
+        q.delta_batch_stride = p.u_batch_stride; q.delta_d_stride = p.u_d_stride; q.delta_l_stride = p.u_l_stride;
+        if (p.io_dtype != ZIGMA_BF16 || !tok_eligible(q) || p.batch > 65535) return ZIGMA_ERR_UNSUPPORTED;
+        return launch_scan_tok_bf16_dtp(q, stream);
+    }
     if (!p.u || !p.delta || !p.A || !p.B || !p.C) return ZIGMA_ERR_NULL;
     if (p.z && !p.out_z) return ZIGMA_ERR_NULL;
     if (!p.z && !p.out) return ZIGMA_ERR_NULL;

@@ -66,20 +66,27 @@ def _as_bgnl(M, name):
 
 def scan_raw(u, delta, A, B, C, D=None, z=None, delta_bias=None, delta_softplus=False, *, out=None, out_z=None,
              x=None, z_row_index=None, out_row_index=None, want_out=True, checkpoints=None, reset_period=0,
-             chunk_len=2048, z_preactivated=False, info=None, _probe_flags=0):
+             chunk_len=2048, z_preactivated=False, info=None, _probe_flags=0, dt_x=None, dt_w=None):
     """Launch zigma_selective_scan_fwd.  All tensors are logical (batch, dim, seqlen) VIEWS with arbitrary
     strides (token-major tensors come in as `.transpose(1, 2)`); B/C are (D, N) f32 or (B, G, N, L) views.
     Outputs that are None are allocated here with the reference's conventions (out like delta, out_z like z).
     z_preactivated: z already holds silu(z) (ZIGMA_SCAN_Z_PREACTIVATED; hot token-major kernel only).
-    info: optional list; receives [kernel family (_lib.SCAN_KERNEL_*), 1 if `checkpoints` is being written]."""
-    dev = _lib.require_device(u, delta, A, B, C, D, z, delta_bias, out, out_z, x, z_row_index, out_row_index)
-    if u.dim() != 3 or delta.shape != u.shape:
+    info: optional list; receives [kernel family (_lib.SCAN_KERNEL_*), 1 if `checkpoints` is being written].
+    dt_x, dt_w (ABI 9, with delta=None): dt_proj + bias + softplus inside the token-major hot kernel — dt_x (batch, seqlen, >= dt_rank)
+    bf16 rows in SCAN order (x_dbl as x_proj wrote it), dt_w (dim, dt_rank); delta' = softplus(dt_x[..., :dt_rank] @ dt_w.T + delta_bias)."""
+    dev = _lib.require_device(u, delta, A, B, C, D, z, delta_bias, out, out_z, x, z_row_index, out_row_index, dt_x, dt_w)
+    if delta is None:
+        if dt_x is None or dt_w is None or not delta_softplus:
+            raise RuntimeError("delta=None needs dt_x, dt_w and delta_softplus=True")
+    elif dt_x is not None or dt_w is not None:
+        raise RuntimeError("pass either delta or (dt_x, dt_w)")
+    if u.dim() != 3 or (delta is not None and delta.shape != u.shape):
         raise RuntimeError("u and delta must both be (batch, dim, seqlen)")
     if A.is_complex():
         raise RuntimeError("zigma_amd: complex A is out of scope (ZigMa's A is real, mamba_simple.py:298)")
     if A.dtype != torch.float32:
         raise RuntimeError("A must be float32")
-    if delta.dtype != u.dtype:
+    if delta is not None and delta.dtype != u.dtype:
         raise RuntimeError("delta must have the dtype of u")
     batch, dim, L = u.shape
     N = A.shape[1]
@@ -140,7 +147,7 @@ def scan_raw(u, delta, A, B, C, D=None, z=None, delta_bias=None, delta_softplus=
         if out_z is None:
             out_z = torch.empty_like(z)
     if out is None and (want_out or z is None):
-        out = torch.empty_like(delta)
+        out = torch.empty_like(delta if delta is not None else u)
     for name, t in (("u", u), ("delta", delta), ("z", z), ("out", out), ("out_z", out_z)):
         if t is None:
             continue
@@ -165,6 +172,12 @@ def scan_raw(u, delta, A, B, C, D=None, z=None, delta_bias=None, delta_softplus=
         if checkpoints.dtype != torch.float32 or not checkpoints.is_contiguous():
             raise RuntimeError("checkpoints must be a contiguous float32 buffer")
         P.checkpoints = _lib.ptr(checkpoints)
+    if dt_x is not None:
+        if (dt_x.dim() != 3 or dt_x.shape[0] != batch or dt_x.shape[1] != L or dt_x.dtype != u.dtype or dt_x.stride(2) != 1
+                or dt_w.dim() != 2 or dt_w.shape[0] != dim or dt_w.dtype != u.dtype or dt_w.stride(1) != 1 or dt_x.shape[2] < dt_w.shape[1]):
+            raise RuntimeError("dt_x must be (batch, seqlen, >= dt_rank) rows and dt_w (dim, dt_rank), both in the dtype of u")
+        P.dt_x, P.dt_w, P.dt_rank = _lib.ptr(dt_x), _lib.ptr(dt_w), dt_w.shape[1]
+        P.dt_x_batch_stride, P.dt_x_l_stride, P.dt_w_row_stride = dt_x.stride(0), dt_x.stride(1), dt_w.stride(0)
     P.reset_period = int(reset_period)       # > 0: independent sequences of that many steps along seqlen
     status = (_lib.C.c_int32 * 2)(0, 0)
     P.info = status                          # host out-field: which kernel family ran, whether it writes the checkpoints
@@ -235,6 +248,19 @@ def conv_x_proj(x_half, conv_w, conv_b, x_proj_weight, perm=None, _flags=0):
     P.u, P.out, P.x_row_index = _lib.ptr(u), _lib.ptr(x_dbl), _lib.ptr(perm)
     _lib.call("zigma_conv_x_proj_fwd", P, dev)
     return u, x_dbl
+
+
+DT_PROJ_IN_SCAN = os.environ.get("ZIGMA_DT_IN_SCAN", "1") == "1"     # dt_proj + softplus in the scan's tile prologue (MFMA) instead of a kernel of its own
+
+
+def dt_in_scan_eligible(u, x_dbl, weight, reset_period=0, out=None):
+    """limits of the in-kernel dt_proj of scan_tok2_kernel (zigma_scan_params_t.dt_x): bf16, whole-sequence mode of the hot kernel
+    (seqlen % 16 == 0, d_inner % 64 == 0, no reset_period), 32 <= dt_rank <= 48 and % 4 == 0, aligned contiguous rows"""
+    R = weight.shape[1]
+    return (u.is_cuda and u.dtype == torch.bfloat16 and x_dbl.dtype == torch.bfloat16 and weight.dtype == torch.bfloat16 and not reset_period
+            and 32 <= R <= 48 and R % 4 == 0 and u.shape[1] % 16 == 0 and u.shape[2] % 64 == 0 and x_dbl.dim() == 3 and x_dbl.shape[2] >= 48
+            and x_dbl.stride(2) == 1 and x_dbl.stride(1) % 8 == 0 and x_dbl.stride(0) % 8 == 0 and weight.stride(1) == 1 and weight.stride(0) % 4 == 0
+            and x_dbl.data_ptr() % 16 == 0 and weight.data_ptr() % 8 == 0 and u.shape[0] <= 65535)
 
 
 def dt_proj_eligible(x_dbl, dt_rank, weight):
@@ -335,6 +361,12 @@ def scan_bwd_tok(u, delta, A, B, C, D, z, delta_bias, dout, out, delta_softplus,
     P = _lib.ScanBwdParams()
     P.batch, P.dim, P.seqlen, P.dstate = Bsz, Dm, L, N
     P.delta_softplus, P.io_dtype, P.flags = int(bool(delta_softplus)), _lib.dtype_id(u), 0
+    if dt_x is not None:
+        if (dt_x.dim() != 3 or dt_x.shape[0] != batch or dt_x.shape[1] != L or dt_x.dtype != u.dtype or dt_x.stride(2) != 1
+                or dt_w.dim() != 2 or dt_w.shape[0] != dim or dt_w.dtype != u.dtype or dt_w.stride(1) != 1 or dt_x.shape[2] < dt_w.shape[1]):
+            raise RuntimeError("dt_x must be (batch, seqlen, >= dt_rank) rows and dt_w (dim, dt_rank), both in the dtype of u")
+        P.dt_x, P.dt_w, P.dt_rank = _lib.ptr(dt_x), _lib.ptr(dt_w), dt_w.shape[1]
+        P.dt_x_batch_stride, P.dt_x_l_stride, P.dt_w_row_stride = dt_x.stride(0), dt_x.stride(1), dt_w.stride(0)
     P.reset_period = int(reset_period)       # > 0: independent sequences of that many steps along seqlen (as in the forward)
     for name, t in (("u", u), ("delta", delta), ("z", z), ("out", out), ("dout", dout), ("du", du), ("ddelta", ddelta),
                     ("dz", dz)):
@@ -550,7 +582,11 @@ def _inner_tok_tail(u, x_dbl, z_half, delta_proj_weight, A, D, delta_bias, perm,
     Bsz, L, Di = u.shape
     R = delta_proj_weight.shape[1]
     N = A.shape[1]
-    if delta_softplus and dt_proj_eligible(x_dbl, R, delta_proj_weight):   # K = dt_rank GEMM + bias + softplus in one write-bound MFMA kernel; scan skips its softplus
+    in_scan = (DT_PROJ_IN_SCAN and delta_softplus and dt_in_scan_eligible(u, x_dbl, delta_proj_weight, reset_period, out)
+               and B_proj_bias is None and C_proj_bias is None and not split_chunk_len(Bsz, Di, L, reset_period))
+    if in_scan:                      # dt_proj + bias + softplus inside the scan kernel's tile prologue: delta is never materialised
+        delta = None
+    elif delta_softplus and dt_proj_eligible(x_dbl, R, delta_proj_weight):   # K = dt_rank GEMM + bias + softplus in one write-bound MFMA kernel; scan skips its softplus
         delta = dt_proj_softplus(x_dbl, R, delta_proj_weight, delta_bias, True)
         delta_bias, delta_softplus = None, False
     else:
@@ -568,8 +604,9 @@ def _inner_tok_tail(u, x_dbl, z_half, delta_proj_weight, A, D, delta_bias, perm,
         xc = torch.empty(Bsz, Di, -(-L // chunk_len), 2 * N, device=u.device, dtype=torch.float32)
     else:
         chunk_len = 2048
-    scan_raw(u.transpose(1, 2), delta.transpose(1, 2), A, Bm.transpose(1, 2).unsqueeze(1),
+    scan_raw(u.transpose(1, 2), None if in_scan else delta.transpose(1, 2), A, Bm.transpose(1, 2).unsqueeze(1),
              Cm.transpose(1, 2).unsqueeze(1), D, z_half.transpose(1, 2), delta_bias, delta_softplus,
              out_z=y.transpose(1, 2), z_row_index=perm, out_row_index=perm if out_rows is None else out_rows,
-             want_out=False, x=xc, reset_period=reset_period, chunk_len=chunk_len, z_preactivated=z_preactivated)
+             want_out=False, x=xc, reset_period=reset_period, chunk_len=chunk_len, z_preactivated=z_preactivated,
+             dt_x=x_dbl if in_scan else None, dt_w=delta_proj_weight if in_scan else None)
     return y
