@@ -414,7 +414,13 @@ def main():
 
     if rank == 0:
         Di, N = 2 * wl["model"]["embed_dim"], 16
-        algo_bytes = batch * L * (4 * 2 * Di + 2 * 2 * N) + 4 * Di * (N + 2)
+        algo_bytes = batch * L * (4 * 2 * Di + 2 * 2 * N) + 4 * Di * (N + 2)       # BASELINE.md §2 / SURVEY §8d, bf16 I/O: u, delta, z, out_z + B, C
+        from zigma_amd import selective_scan_interface as _ssi
+        R = -(-wl["model"]["embed_dim"] // 16)
+        dt_in = _ssi.DT_PROJ_IN_SCAN and not _ssi.split_chunk_len(batch, Di, L)
+        # with dt_proj + softplus inside the kernel (round 4) the delta stream does not exist: what the launch really moves is
+        # u, z, out_z + the x_dbl row (dt columns, B, C) + W_dt
+        moved_bytes = batch * L * (3 * 2 * Di + 2 * (R + 2 * N)) + 4 * Di * (N + 2) + 2 * Di * R if dt_in else algo_bytes
         roof = None
         if timer.pairs:
             ms = timer.mean_ms()
@@ -430,10 +436,12 @@ def main():
             # wave instruction per SIMD — v_exp_f32 3.43, v_pk_mul/fma_f32 2.28 for two results, plain VOP2 1.35): per 4 states
             # 4 exp + 6 packed + 4 plain = 32.8 ns
             valu_floor_measured_us = groups / 4 * (4 * 3.43 + 6 * 2.28 + 4 * 1.35) * 1e-9 / 1024 * 1e6
-            roof = dict(bound="hbm", kernel="scan_tok (fused zigzag selective scan)", achieved=ach / 1e9,
+            roof = dict(bound="hbm", kernel="scan_tok2 (fused zigzag selective scan" + (", dt_proj + softplus inside" if dt_in else "") + ")", achieved=ach / 1e9,
                         peak=HBM_PEAK / 1e9, unit="GB/s", frac=ach / HBM_PEAK, traffic=traffic,
                         traffic_source=traffic_src, launch_us=ms * 1e3, launches=len(timer.pairs),
-                        algorithmic_bytes=algo_bytes, limiter="valu", valu_floor_us=valu_floor_us,
+                        algorithmic_bytes=algo_bytes, algorithmic_bytes_note="SURVEY 8(d) formula of the selective scan (u, delta, z, out_z, B, C)",
+                        bytes_moved_by_design=moved_bytes, frac_of_bytes_moved=moved_bytes / (ms * 1e-3) / HBM_PEAK,
+                        dt_proj_inside=bool(dt_in), limiter="valu", valu_floor_us=valu_floor_us,
                         valu_frac=valu_floor_us / (ms * 1e3), valu_floor_measured_rates_us=valu_floor_measured_us,
                         valu_frac_measured_rates=valu_floor_measured_us / (ms * 1e3),
                         valu_rates_source="profiles/r02_ubench2_valu_rates.txt (tools/ubench2: ns per wave-instruction per SIMD)")

@@ -126,7 +126,8 @@ typedef struct zigma_scan_params {
      * is formed by the workgroup itself (v_mfma_f32_16x16x32_bf16 in the tile prologue) from the dt columns of the x_dbl rows it
      * already fetches B_l / C_l from — the (batch, seqlen, dim) delta tensor (reference selective_scan_interface.py:323) is
      * neither written nor read.  dt_x: rows of scan position l (row pitch dt_x_l_stride, 16-byte aligned), dt_w: (dim, dt_rank)
-     * rows of pitch dt_w_row_stride; dt_rank % 4 == 0, <= 48.  delta_softplus must be 1. */
+     * rows of pitch dt_w_row_stride (16-byte aligned); 32 <= dt_rank <= 64, dt_rank % 8 == 0, dt_x rows at least 64 wide.
+     * delta_softplus must be 1. */
     const void *dt_x, *dt_w;
     int64_t dt_x_batch_stride, dt_x_l_stride, dt_w_row_stride;
     int32_t dt_rank, pad3_;

@@ -96,7 +96,7 @@ def _trace_counts(trace):
     return counts, gated
 
 
-@pytest.mark.parametrize("variant", ["default", "unfused_out_proj", "linear_all", "linear_off"])
+@pytest.mark.parametrize("variant", ["default", "unfused_out_proj", "linear_all", "linear_off", "default_b32"])
 def test_bench_block_path_vs_reference(variant, monkeypatch):
     """The composition bench.py times: README model, bf16, B = 16 -> 16 384 tokens, so that every size
     gate of the hot path opens — the one-pass conv + x_proj kernel, out_proj with the block's gated add in its epilogue
@@ -110,7 +110,7 @@ def test_bench_block_path_vs_reference(variant, monkeypatch):
     from zigma_amd import _lib
     m, g, cfg, y2 = _r2_model("r2_readme_b2", torch.bfloat16)
     depth = cfg["depth"]
-    Bsz = 16
+    Bsz = 32 if variant == "default_b32" else 16      # 32 768 tokens: in_proj as two half-width launches of the own kernel (round 4)
     gen = torch.Generator().manual_seed(99)
     x = torch.randn(Bsz, *g["x"].shape[1:], generator=gen)
     t = torch.rand(Bsz, generator=gen)
@@ -133,13 +133,26 @@ def test_bench_block_path_vs_reference(variant, monkeypatch):
     assert counts.get(("zigma_conv_x_proj_fwd", "conv_x_proj_mfma"), 0) == depth, counts
     assert sum(c for (fn, k), c in counts.items() if fn == "zigma_selective_scan_fwd" and k.startswith("scan_tok2")) == depth, counts
     assert counts.get(("zigma_cross_attn_fwd", "cross_attn_mfma"), 0) == depth, counts
-    if variant == "default":
+    n_text = sum(1 for fn, _, P in trace if fn == "zigma_linear_fwd" and P.m % 256 == 0 and P.m < Bsz * 1024)      # y_embedder, batched K / V (padded rows)
+    E = cfg["embed_dim"]
+    n_in_halves = sum(1 for fn, _, P in trace if fn == "zigma_linear_fwd" and P.k == E and P.n == 2 * E and P.m == Bsz * 1024)
+    dt_in_scan = counts.get(("zigma_selective_scan_fwd", "scan_tok2_n16_dtproj"), 0)
+    n_dt = counts.get(("zigma_dt_proj_softplus_fwd", "dt_proj_softplus_mfma"), 0)
+    if Bsz * (2 * E // 64) >= 768:      # whole-sequence mode of the hot scan kernel: dt_proj + softplus inside it (round 4)
+        assert dt_in_scan == depth and n_dt == 0, counts
+    else:                               # sequence-split mode (small batches): the dt_proj kernel of its own
+        assert dt_in_scan == 0 and n_dt == depth, counts
+    if variant in ("default", "default_b32"):
         assert gated == 2 * depth, (gated, counts)          # out_proj + to_out, every block
-        assert n_lin >= 2 * depth
+        assert n_text == 2, (n_text, counts)                # no library GEMM on the text side either
+        if variant == "default_b32":                        # every projection of the block loop on the own kernel: 2 in_proj halves + out_proj + to_q + to_out
+            assert n_in_halves == 2 * depth and n_lin == 5 * depth + 2, (n_in_halves, n_lin, counts)
+        else:
+            assert n_lin >= 3 * depth + 2
     elif variant == "unfused_out_proj":
         assert gated == depth, (gated, counts)              # to_out only
     elif variant == "linear_all":
-        assert gated == 2 * depth and n_lin == 4 * depth, (gated, n_lin, counts)    # in_proj, out_proj, to_q, to_out
+        assert gated == 2 * depth and n_lin == 4 * depth + 2, (gated, n_lin, counts)    # in_proj, out_proj, to_q, to_out (+ the 2 text-side products)
     else:
         assert n_lin == 0 and gated == 0, counts
     got = N(out)[[0, Bsz - 1]]
@@ -217,15 +230,17 @@ def _dev_weights(w):
             t(w["A"], torch.float32), t(w["D"], torch.float32), t(w["dt_bias"], torch.float32))
 
 
-def _oracle_sample_stages(xz_b, w, perm, R, Nst):
+def _oracle_sample_stages(xz_b, w, perm, R, Nst, round_delta=True):
     """One sample through conv -> x_proj -> dt_proj (+ softplus) in fp32 with bf16 rounding where the bf16 pipeline stores
-    (selective_scan_interface.py:316-323 on bf16 tensors): returns u, x_dbl, delta in SCAN order, (L, .) each."""
+    (selective_scan_interface.py:316-323 on bf16 tensors): returns u, x_dbl, delta in SCAN order, (L, .) each.
+    round_delta=False: the step size stays in fp32 — dt_proj + softplus inside the scan kernel (round 4; the whole-sequence mode of
+    the hot kernel), where no delta tensor exists."""
     Di = w["conv_w"].shape[0]
     xs = xz_b[perm, :Di]
     u = bf(zo.causal_conv1d(xs.T[None], w["conv_w"], w["conv_b"], "silu")[0].T)
     x_dbl = bf((u.astype(np.float64) @ w["x_proj_w"].astype(np.float64).T).astype(np.float32))
-    delta = bf(zo.softplus((x_dbl[:, :R].astype(np.float64) @ w["dt_proj_w"].astype(np.float64).T).astype(np.float32) + w["dt_bias"]))
-    return u, x_dbl, delta
+    delta = zo.softplus((x_dbl[:, :R].astype(np.float64) @ w["dt_proj_w"].astype(np.float64).T).astype(np.float32) + w["dt_bias"])
+    return u, x_dbl, (bf(delta) if round_delta else delta)
 
 
 def _oracle_slab(xz_b, u, x_dbl, delta, w, perm, out_rows, sl, R, Nst):
@@ -259,7 +274,7 @@ def test_config2_mamba_inner_full_size_bf16():
     worst = 0.0
     for b, slab in ((0, 0), (17, 7), (40, 13), (63, 19)):
         xz_b = xz[b].float().numpy()
-        u, x_dbl, delta = _oracle_sample_stages(xz_b, w, perm, R, Nst)
+        u, x_dbl, delta = _oracle_sample_stages(xz_b, w, perm, R, Nst, round_delta=False)      # B = 64: dt_proj inside the scan
         sl = slice(slab * 64, slab * 64 + 64)
         ref = _oracle_slab(xz_b, u, x_dbl, delta, w, perm, perm, sl, R, Nst)
         err = rel_err(N(y[b, :, sl]), ref)

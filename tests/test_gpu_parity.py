@@ -447,6 +447,7 @@ def test_scan_tok2_dt_proj_in_kernel_vs_oracle(Bsz, L, Di, R, use_perm):
     from zigma_amd import _lib
     from zigma_amd.selective_scan_interface import dt_in_scan_eligible, dt_proj_softplus, scan_raw
     Nst = 16
+    bf = zo.bf16_round
     rng = np.random.default_rng(Bsz * 1000 + L + R)
     u = bf(rng.standard_normal((Bsz, L, Di)).astype(np.float32))
     z = bf(rng.standard_normal((Bsz, L, Di)).astype(np.float32))

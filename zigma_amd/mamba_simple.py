@@ -22,7 +22,7 @@ from .wgrad import linear_train
 NO_COPY_TEMPORAL = True      # video "t" layers on strided views (False: the transposing-copy form; A/B in the tests)
 
 
-IN_PROJ_SPLIT = os.environ.get("ZIGMA_IN_PROJ_SPLIT", "0") == "1"      # in_proj as two half-width launches of the own kernel
+IN_PROJ_SPLIT = os.environ.get("ZIGMA_IN_PROJ_SPLIT", "1") == "1"      # in_proj as two half-width launches of the own kernel
 IN_PROJ_SPLIT_MIN_TOKENS = 32768
 
 

@@ -275,6 +275,26 @@ class Pending:
 # GEMM + the add inside the following norm kernel.  Per block (profiles/r02_b_bench_kernel_stats.csv vs r02_d_*): out_proj 127 -> 150 us,
 # pre-attention add + norm 68 -> 47, and with to_out's gated add: to_out 63 -> 78, pre-mixer add + norm 119 -> 102 — time moves from
 # the HBM-bound norm kernels into the projection epilogues, the forward is 0.1-0.3 % faster.
+TEXT_PROJ_OWN = True           # y_embedder and the batched K / V projection of all blocks (B x 77 text rows) on zigma_linear_fwd, rows padded to 256
+
+
+def _padded_own_linear(x, weight, bias):
+    """x @ weight.T (+ bias) for a row count the projection kernel's 256-row tiles do not divide (B x 77 text tokens): the rows are
+    copied into a zero-padded buffer, the kernel runs on the padded count, the real rows come back as a view.  None when the own
+    kernel does not take the operands (then the caller keeps F.linear).  Reference call sites: model_zigma.py:668 (y_embedder),
+    :104-112 (to_k / to_v of every block, here one batched product)."""
+    if not (x.is_cuda and x.dtype == torch.bfloat16) or (torch.is_grad_enabled() and (x.requires_grad or weight.requires_grad)):
+        return None
+    k = x.shape[-1]
+    m = x.numel() // k
+    mp = -(-m // 256) * 256
+    xp = x.new_zeros(mp, k)
+    xp[:m] = x.reshape(m, k)
+    if not linear_eligible(xp, weight, bias, prefer_own=True):
+        return None
+    return linear(xp, weight, bias)[:m].view(*x.shape[:-1], weight.shape[0])
+
+
 FUSE_OUT_PROJ_ADD = True       # (module-level knob for tests / tools; no environment switch)
 FUSE_OUT_PROJ_ADD_NO_TEXT = True     # the same for blocks without the attention branch (tools/outproj_notext_ab.py: 14.82 -> 14.78 ms on config 3's model)
 
@@ -566,7 +586,9 @@ class ZigMa(nn.Module):
         t = (t * 1000.0).to(hidden_states)
         t = self.t_embedder(t)                                                  # (N, D)
         if self.has_text:
-            y = self.y_embedder(y.to(pdtype))                                   # (B, n_ctx, D)
+            yp = y.to(pdtype)
+            ye = _padded_own_linear(yp, self.y_embedder.weight, self.y_embedder.bias) if TEXT_PROJ_OWN else None
+            y = ye if ye is not None else self.y_embedder(yp)                   # (B, n_ctx, D)
             c = t + y.mean(dim=1)
         elif self.num_classes > 0:
             c = t + self.y_embedder(y, self.training)
@@ -647,7 +669,8 @@ class ZigMa(nn.Module):
         kvs = None
         if self.has_text:
             inner = blocks[0].msa.to_k.weight.shape[0]
-            kv_all = F.linear(text, Wkv).view(text.shape[0], text.shape[1], n, 2, inner)
+            kv_own = _padded_own_linear(text, Wkv, None) if TEXT_PROJ_OWN else None
+            kv_all = (kv_own if kv_own is not None else F.linear(text, Wkv)).view(text.shape[0], text.shape[1], n, 2, inner)
             kvs = [(kv_all[:, :, i, 0], kv_all[:, :, i, 1]) for i in range(n)]
         return mods, kvs
 
