@@ -138,7 +138,8 @@ def test_bench_block_path_vs_reference(variant, monkeypatch):
     n_in_halves = sum(1 for fn, _, P in trace if fn == "zigma_linear_fwd" and P.k == E and P.n == 2 * E and P.m == Bsz * 1024)
     dt_in_scan = counts.get(("zigma_selective_scan_fwd", "scan_tok2_n16_dtproj"), 0)
     n_dt = counts.get(("zigma_dt_proj_softplus_fwd", "dt_proj_softplus_mfma"), 0)
-    if Bsz * (2 * E // 64) >= 768:      # whole-sequence mode of the hot scan kernel: dt_proj + softplus inside it (round 4)
+    from zigma_amd.selective_scan_interface import split_chunk_len
+    if not split_chunk_len(Bsz, 2 * E, 1024):      # whole-sequence mode of the hot scan kernel: dt_proj + softplus inside it (round 4)
         assert dt_in_scan == depth and n_dt == 0, counts
     else:                               # sequence-split mode (small batches): the dt_proj kernel of its own
         assert dt_in_scan == 0 and n_dt == depth, counts
@@ -148,7 +149,7 @@ def test_bench_block_path_vs_reference(variant, monkeypatch):
         if variant == "default_b32":                        # every projection of the block loop on the own kernel: 2 in_proj halves + out_proj + to_q + to_out
             assert n_in_halves == 2 * depth and n_lin == 5 * depth + 2, (n_in_halves, n_lin, counts)
         else:
-            assert n_lin >= 3 * depth + 2
+            assert n_lin >= 2 * depth + 2               # (at 16 384 tokens to_q stays on the library: too few tiles for the 4-wave kernel)
     elif variant == "unfused_out_proj":
         assert gated == depth, (gated, counts)              # to_out only
     elif variant == "linear_all":

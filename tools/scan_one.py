@@ -11,7 +11,14 @@ A = -torch.exp(torch.log(torch.arange(1, N + 1, device=dev).float()) + 0.1 * tor
 D = torch.randn(Di, device=dev); perm = torch.randperm(L, device=dev).to(torch.int32)
 y = torch.empty(B, L, Di, device=dev, dtype=dt)
 Bv = xdbl[:, :, R:R + N].transpose(1, 2).unsqueeze(1); Cv = xdbl[:, :, R + N:].transpose(1, 2).unsqueeze(1)
+from zigma_amd import selective_scan_interface as ssi
+dt_in = ssi.DT_PROJ_IN_SCAN and os.environ.get("DT_IN", "1") == "1"      # as the model launches it since round 4: dt_proj + softplus inside
+w_dt = (R ** -0.5 * torch.randn(Di, R, device=dev)).to(dt); db = torch.randn(Di, device=dev) - 3
 for _ in range(int(os.environ.get("N", 20))):
-    scan_raw(u.transpose(1, 2), delta.transpose(1, 2), A, Bv, Cv, D, xz[:, :, Di:].transpose(1, 2), None, False,
-             out_z=y.transpose(1, 2), z_row_index=perm, out_row_index=perm, want_out=False)
+    if dt_in:
+        scan_raw(u.transpose(1, 2), None, A, Bv, Cv, D, xz[:, :, Di:].transpose(1, 2), db, True,
+                 out_z=y.transpose(1, 2), z_row_index=perm, out_row_index=perm, want_out=False, dt_x=xdbl, dt_w=w_dt)
+    else:
+        scan_raw(u.transpose(1, 2), delta.transpose(1, 2), A, Bv, Cv, D, xz[:, :, Di:].transpose(1, 2), None, False,
+                 out_z=y.transpose(1, 2), z_row_index=perm, out_row_index=perm, want_out=False)
 torch.cuda.synchronize()

@@ -18,6 +18,7 @@ What is different underneath (sampling / eval forward):
     in the input dtype, so an fp32 ODE state can drive a bf16 model.
 """
 import math
+import os
 from functools import partial
 from typing import Optional
 
@@ -275,7 +276,7 @@ class Pending:
 # GEMM + the add inside the following norm kernel.  Per block (profiles/r02_b_bench_kernel_stats.csv vs r02_d_*): out_proj 127 -> 150 us,
 # pre-attention add + norm 68 -> 47, and with to_out's gated add: to_out 63 -> 78, pre-mixer add + norm 119 -> 102 — time moves from
 # the HBM-bound norm kernels into the projection epilogues, the forward is 0.1-0.3 % faster.
-TEXT_PROJ_OWN = True           # y_embedder and the batched K / V projection of all blocks (B x 77 text rows) on zigma_linear_fwd, rows padded to 256
+TEXT_PROJ_OWN = os.environ.get("ZIGMA_TEXT_PROJ_OWN", "1") == "1"   # y_embedder and the batched K / V projection of all blocks (B x 77 text rows) on zigma_linear_fwd, rows padded to 256
 
 
 def _padded_own_linear(x, weight, bias):

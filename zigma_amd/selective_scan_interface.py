@@ -361,12 +361,6 @@ def scan_bwd_tok(u, delta, A, B, C, D, z, delta_bias, dout, out, delta_softplus,
     P = _lib.ScanBwdParams()
     P.batch, P.dim, P.seqlen, P.dstate = Bsz, Dm, L, N
     P.delta_softplus, P.io_dtype, P.flags = int(bool(delta_softplus)), _lib.dtype_id(u), 0
-    if dt_x is not None:
-        if (dt_x.dim() != 3 or dt_x.shape[0] != batch or dt_x.shape[1] != L or dt_x.dtype != u.dtype or dt_x.stride(2) != 1
-                or dt_w.dim() != 2 or dt_w.shape[0] != dim or dt_w.dtype != u.dtype or dt_w.stride(1) != 1 or dt_x.shape[2] < dt_w.shape[1]):
-            raise RuntimeError("dt_x must be (batch, seqlen, >= dt_rank) rows and dt_w (dim, dt_rank), both in the dtype of u")
-        P.dt_x, P.dt_w, P.dt_rank = _lib.ptr(dt_x), _lib.ptr(dt_w), dt_w.shape[1]
-        P.dt_x_batch_stride, P.dt_x_l_stride, P.dt_w_row_stride = dt_x.stride(0), dt_x.stride(1), dt_w.stride(0)
     P.reset_period = int(reset_period)       # > 0: independent sequences of that many steps along seqlen (as in the forward)
     for name, t in (("u", u), ("delta", delta), ("z", z), ("out", out), ("dout", dout), ("du", du), ("ddelta", ddelta),
                     ("dz", dz)):
