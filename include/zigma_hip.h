@@ -121,7 +121,7 @@ typedef struct zigma_scan_params {
     /* optional HOST pointer to int32[2], written by the call before it returns (never by a kernel):
      * info[0] = ZIGMA_SCAN_KERNEL_* that was launched, info[1] = 1 iff `checkpoints` is being written. */
     int32_t *info;
-    /* ABI 9 — dt_proj INSIDE the scan (token-major hot kernel, bf16, whole-sequence mode only): when dt_x != NULL, `delta` is ignored and
+    /* ABI 9 — dt_proj INSIDE the scan (token-major hot kernel, bf16 / fp16, whole-sequence mode only): when dt_x != NULL, `delta` is ignored and
      *   delta'[b, l, d] = softplus( sum_{r < dt_rank} dt_x[b, l, r] * dt_w[d, r] + delta_bias[d] )
      * is formed by the workgroup itself (v_mfma_f32_16x16x32_bf16 in the tile prologue) from the dt columns of the x_dbl rows it
      * already fetches B_l / C_l from — the (batch, seqlen, dim) delta tensor (reference selective_scan_interface.py:323) is

@@ -96,7 +96,7 @@ def _trace_counts(trace):
     return counts, gated
 
 
-@pytest.mark.parametrize("variant", ["default", "unfused_out_proj", "linear_all", "linear_off", "default_b32"])
+@pytest.mark.parametrize("variant", ["default", "unfused_out_proj", "linear_all", "linear_off", "default_b32", "in_proj_halves_b32"])
 def test_bench_block_path_vs_reference(variant, monkeypatch):
     """The composition bench.py times: README model, bf16, B = 16 -> 16 384 tokens, so that every size
     gate of the hot path opens — the one-pass conv + x_proj kernel, out_proj with the block's gated add in its epilogue
@@ -110,7 +110,7 @@ def test_bench_block_path_vs_reference(variant, monkeypatch):
     from zigma_amd import _lib
     m, g, cfg, y2 = _r2_model("r2_readme_b2", torch.bfloat16)
     depth = cfg["depth"]
-    Bsz = 32 if variant == "default_b32" else 16      # 32 768 tokens: in_proj as two half-width launches of the own kernel (round 4)
+    Bsz = 32 if variant.endswith("_b32") else 16      # 32 768 tokens: in_proj on the weight-stationary kernel / as two half-width launches (round 4)
     gen = torch.Generator().manual_seed(99)
     x = torch.randn(Bsz, *g["x"].shape[1:], generator=gen)
     t = torch.rand(Bsz, generator=gen)
@@ -123,6 +123,9 @@ def test_bench_block_path_vs_reference(variant, monkeypatch):
         monkeypatch.setattr(zl, "LINEAR_POLICY", "all")
     elif variant == "linear_off":
         monkeypatch.setattr(zl, "LINEAR_POLICY", "off")
+    elif variant == "in_proj_halves_b32":
+        import zigma_amd.mamba_simple as zms
+        monkeypatch.setattr(zms, "IN_PROJ_WS", False)
     trace = []
     monkeypatch.setattr(_lib, "TRACE", trace)
     with torch.no_grad():
@@ -143,11 +146,14 @@ def test_bench_block_path_vs_reference(variant, monkeypatch):
         assert dt_in_scan == depth and n_dt == 0, counts
     else:                               # sequence-split mode (small batches): the dt_proj kernel of its own
         assert dt_in_scan == 0 and n_dt == depth, counts
-    if variant in ("default", "default_b32"):
+    n_ws = counts.get(("zigma_linear_fwd", "linear_ws"), 0)
+    if variant in ("default", "default_b32", "in_proj_halves_b32"):
         assert gated == 2 * depth, (gated, counts)          # out_proj + to_out, every block
         assert n_text == 2, (n_text, counts)                # no library GEMM on the text side either
-        if variant == "default_b32":                        # every projection of the block loop on the own kernel: 2 in_proj halves + out_proj + to_q + to_out
-            assert n_in_halves == 2 * depth and n_lin == 5 * depth + 2, (n_in_halves, n_lin, counts)
+        if variant == "default_b32":                        # every projection of the block loop on an own kernel: in_proj (weight-stationary) + out_proj + to_q + to_out
+            assert n_ws == depth and n_in_halves == 0 and n_lin == 4 * depth + 2, (n_ws, n_in_halves, n_lin, counts)
+        elif variant == "in_proj_halves_b32":               # ... with in_proj as two half-width launches of the tiled kernel
+            assert n_ws == 0 and n_in_halves == 2 * depth and n_lin == 5 * depth + 2, (n_in_halves, n_lin, counts)
         else:
             assert n_lin >= 2 * depth + 2               # (at 16 384 tokens to_q stays on the library: too few tiles for the 4-wave kernel)
     elif variant == "unfused_out_proj":

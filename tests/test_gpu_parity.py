@@ -440,14 +440,16 @@ def test_dt_proj_softplus_mfma_vs_oracle(M, Di, R, S):
 
 @pytest.mark.parametrize("Bsz,L,Di,R,use_perm", [(2, 64, 128, 40, False), (3, 1024, 192, 40, True), (2, 256, 64, 48, True),
                                                  (5, 48, 1280, 40, True), (1, 16, 64, 32, False)])
-def test_scan_tok2_dt_proj_in_kernel_vs_oracle(Bsz, L, Di, R, use_perm):
+@pytest.mark.parametrize("io", ["bf16", "f16"])
+def test_scan_tok2_dt_proj_in_kernel_vs_oracle(Bsz, L, Di, R, use_perm, io):
     """ABI 9: dt_proj + bias + softplus inside scan_tok2_kernel (zigma_scan_params_t.dt_x / dt_w) against the numpy oracle's scan on
     delta' = x_dbl[:, :, :R] @ W_dt^T (reference selective_scan_interface.py:323 + softplus(delta + bias) of its kernel) evaluated in
     fp32 on the same bf16 operands, and against the two-kernel path (dt_proj_softplus_kernel + scan) whose delta is a bf16 tensor."""
     from zigma_amd import _lib
     from zigma_amd.selective_scan_interface import dt_in_scan_eligible, dt_proj_softplus, scan_raw
     Nst = 16
-    bf = zo.bf16_round
+    tdt = torch.bfloat16 if io == "bf16" else torch.float16
+    bf = zo.bf16_round if io == "bf16" else (lambda a: np.asarray(a, np.float32).astype(np.float16).astype(np.float32))
     rng = np.random.default_rng(Bsz * 1000 + L + R)
     u = bf(rng.standard_normal((Bsz, L, Di)).astype(np.float32))
     z = bf(rng.standard_normal((Bsz, L, Di)).astype(np.float32))
@@ -458,12 +460,12 @@ def test_scan_tok2_dt_proj_in_kernel_vs_oracle(Bsz, L, Di, R, use_perm):
     db = (rng.standard_normal(Di) - 3.0).astype(np.float32)
     db[0] = 26.0                                                  # softplus pass-through branch (> 20)
     perm = np.random.default_rng(9).permutation(L).astype(np.int64) if use_perm else None
-    ut, zt, xt = T(u, torch.bfloat16), T(z, torch.bfloat16), T(xd, torch.bfloat16)
-    wt = T(w, torch.bfloat16)
+    ut, zt, xt = T(u, tdt), T(z, tdt), T(xd, tdt)
+    wt = T(w, tdt)
     pt = None if perm is None else torch.from_numpy(perm).to(DEV).to(torch.int32)
     assert dt_in_scan_eligible(ut, xt, wt)
     Bv, Cv = xt[:, :, R:R + Nst].transpose(1, 2).unsqueeze(1), xt[:, :, R + Nst:].transpose(1, 2).unsqueeze(1)
-    y = torch.empty(Bsz, L, Di, device=DEV, dtype=torch.bfloat16)
+    y = torch.empty(Bsz, L, Di, device=DEV, dtype=tdt)
     info = []
     scan_raw(ut.transpose(1, 2), None, T(A), Bv, Cv, T(D), zt.transpose(1, 2), T(db), True, out_z=y.transpose(1, 2),
              z_row_index=pt, out_row_index=pt, want_out=False, dt_x=xt, dt_w=wt, info=info)
@@ -480,6 +482,8 @@ def test_scan_tok2_dt_proj_in_kernel_vs_oracle(Bsz, L, Di, R, use_perm):
     assert np.isfinite(got).all() and e < 1e-3, e
     assert np.allclose(got, ref, rtol=3e-2, atol=5e-2)           # the reference's bf16 bounds (test_selective_scan.py:47)
     # the path it replaces
+    if io != "bf16":
+        return                                                   # (zigma_dt_proj_softplus_fwd is a bf16 kernel)
     dl = dt_proj_softplus(xt, R, wt, T(db), True)
     y2 = torch.empty_like(y)
     scan_raw(ut.transpose(1, 2), dl.transpose(1, 2), T(A), Bv, Cv, T(D), zt.transpose(1, 2), None, False, out_z=y2.transpose(1, 2),
@@ -922,6 +926,54 @@ def test_linear4w_kernel(M, K, N, monkeypatch):
         linear(x, w, out=wide[:, 128:128 + N])
         assert _lib.last_kernel() == "linear4w_256x256"
         assert torch.equal(wide[:, 128:128 + N], y) and float(wide[:, :128].abs().max()) == 0 and float(wide[:, 128 + N:].abs().max()) == 0
+
+
+@pytest.mark.parametrize("M,K,N", [(65536, 640, 2560), (65536, 640, 512), (32768, 640, 2560), (4096, 640, 8192), (5632, 512, 1024), (512 * 43, 384, 256),
+                                   (16384, 640, 1280)])
+def test_linear_ws_kernel(M, K, N):
+    """The weight-stationary projection kernel (csrc/linear_ws.hip; in_proj of the default path, reference mamba_simple.py:290-294): every
+    output of sampled rows against float64 on the same bf16 operands; the WHOLE result bit-identical with the tiled kernel (same MFMA, same
+    accumulation order over k) — which covers every tile, range and panel boundary, odd and even tile counts per workgroup (the epilogue
+    rides in the next tile's k-loop; the last one has its own path); run-to-run identity; a strided output; the limits."""
+    from zigma_amd import _lib
+    from zigma_amd.linear import linear, linear_ws_eligible
+    g = torch.Generator(device="cpu").manual_seed(M + N + K)
+    x = torch.randn(M, K, generator=g).to(DEV, torch.bfloat16)
+    w = (torch.randn(N, K, generator=g) * K ** -0.5).to(DEV, torch.bfloat16)
+    assert linear_ws_eligible(x, w)
+    y = linear(x, w, weight_stationary=True)
+    assert _lib.last_kernel() == "linear_ws" and y.shape == (M, N)
+    rows = torch.randint(0, M, (1024,), generator=g).to(DEV)
+    rows[:6] = torch.tensor([0, 63, 64, 511, 512, M - 1], device=DEV)
+    ref = x[rows].double() @ w.double().T
+    got = y[rows].double()
+    assert float((got - ref).norm() / ref.norm()) < 2.5e-3
+    assert torch.allclose(got, ref, rtol=1.6e-2, atol=1e-2)
+    y8 = linear(x, w, _probe_flags=0x2000)
+    assert _lib.last_kernel().startswith("linear_tn_")
+    assert torch.equal(y, y8)
+    for _ in range(4):
+        assert torch.equal(linear(x, w, weight_stationary=True), y)
+    wide = torch.zeros(M, N + 256, device=DEV, dtype=torch.bfloat16)
+    linear(x, w, out=wide[:, 128:128 + N], weight_stationary=True)
+    assert _lib.last_kernel() == "linear_ws"
+    assert torch.equal(wide[:, 128:128 + N], y) and float(wide[:, :128].abs().max()) == 0 and float(wide[:, 128 + N:].abs().max()) == 0
+    xs = torch.zeros(M, K + 128, device=DEV, dtype=torch.bfloat16)          # rows of the input 128 elements further apart
+    xs[:, :K] = x
+    assert torch.equal(linear(xs[:, :K], w, weight_stationary=True), y)
+
+
+def test_linear_ws_limits():
+    from zigma_amd.linear import linear, linear_ws_eligible
+    x = torch.randn(4096, 640, device=DEV).bfloat16()
+    for w, xx in ((torch.randn(384, 640, device=DEV).bfloat16(), x),               # n % 256
+                  (torch.randn(512, 768, device=DEV).bfloat16(), torch.randn(4096, 768, device=DEV).bfloat16()),      # k > 640
+                  (torch.randn(512, 640, device=DEV).bfloat16(), x[:4000])):       # tokens % 512
+        assert not linear_ws_eligible(xx, w)
+        with pytest.raises(RuntimeError):
+            linear(xx, w, weight_stationary=True)
+    with pytest.raises(RuntimeError):                                              # no epilogue operands in this kernel
+        linear(x, torch.randn(512, 640, device=DEV).bfloat16(), torch.zeros(512, device=DEV).bfloat16(), weight_stationary=True)
 
 
 @pytest.mark.parametrize("Bsz,L,K,N,bias,res", [(64, 1024, 1280, 640, False, False), (64, 1024, 1280, 640, False, True), (64, 1024, 512, 640, True, True),

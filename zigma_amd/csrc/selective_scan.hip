@@ -122,6 +122,7 @@ __global__ __launch_bounds__(64) void scan_generic_kernel(const zigma_scan_param
 int launch_scan_tok_bf16(const zigma_scan_params_t &p, hipStream_t stream);
 int launch_scan_tok_bf16_dtp(const zigma_scan_params_t &p, hipStream_t stream);
 int launch_scan_tok_f16(const zigma_scan_params_t &p, hipStream_t stream);
+int launch_scan_tok_f16_dtp(const zigma_scan_params_t &p, hipStream_t stream);
 int launch_scan_tok_f32(const zigma_scan_params_t &p, hipStream_t stream);
 
 // =================================================================================================
@@ -195,8 +196,8 @@ extern "C" int zigma_selective_scan_fwd(const zigma_scan_params_t *pp, void *str
         zigma_scan_params_t q = p;
         q.delta = p.u;
         q.delta_batch_stride = p.u_batch_stride; q.delta_d_stride = p.u_d_stride; q.delta_l_stride = p.u_l_stride;
-        if (p.io_dtype != ZIGMA_BF16 || !tok_eligible(q) || p.batch > 65535) return ZIGMA_ERR_UNSUPPORTED;
-        return launch_scan_tok_bf16_dtp(q, stream);
+        if ((p.io_dtype != ZIGMA_BF16 && p.io_dtype != ZIGMA_F16) || !tok_eligible(q) || p.batch > 65535) return ZIGMA_ERR_UNSUPPORTED;
+        return p.io_dtype == ZIGMA_BF16 ? launch_scan_tok_bf16_dtp(q, stream) : launch_scan_tok_f16_dtp(q, stream);
     }
     if (!p.u || !p.delta || !p.A || !p.B || !p.C) return ZIGMA_ERR_NULL;
     if (p.z && !p.out_z) return ZIGMA_ERR_NULL;

@@ -10,10 +10,12 @@ import os
 # Which projections run on zigma_linear_fwd.  Measured at the headline shapes (M = 65 536 tokens), own 4-wave kernel (csrc/linear4w.hip)
 # vs hipBLASLt in us (profiles/r03_e_linear4w_probe.jsonl, r03_n_linear4w_epilogue_probe.jsonl; in the forward r03_t_bench_kernel_stats.csv):
 #   out_proj + gated add 122 vs 116 + the add in the norm kernel;  to_out + bias + gated add 54 (67 in the forward) vs 70;
-#   to_q 46-47 vs 44-47 (a tie);  the whole in_proj (N = 2560) 222 vs 200 — which is why round 4 no longer runs it as ONE projection:
-#   its x half lives inside zigma_in_conv_x_proj_fwd (selective_scan_interface.in_conv_x_proj) and only the z half (N = 1280) is a GEMM.
+#   to_q 46-47 vs 44-47 (a tie);  the whole in_proj (N = 2560) 222 vs 200 as ONE launch, 2 x 104-105 as two half-width launches
+#   (N = 1280 each; mamba_simple.IN_PROJ_SPLIT, round 4 — the default, +1.8 % on the forward against the library).
+#   Round 4, in_proj as ONE launch again: the weight-stationary kernel (csrc/linear_ws.hip; mamba_simple.IN_PROJ_WS) 184-196 us.
 #   "auto" (default): every projection of the inference path the own kernel serves at least as fast as the library (to_q, to_out,
-#   out_proj with the block's gated add, the z half of in_proj);  "all": every eligible projection;  "off": library only.
+#   out_proj with the block's gated add) — plus the in_proj halves, which the caller requests with prefer_own;
+#   "all": every eligible projection;  "off": library only.
 LINEAR_POLICY = os.environ.get("ZIGMA_LINEAR", "auto")
 
 
@@ -51,11 +53,26 @@ def linear_eligible(x, weight, bias=None, fused_epilogue=False, prefer_own=False
     return m * x.stride(-2) * 2 < 2 ** 31 and n * weight.stride(0) * 2 < 2 ** 31 and 256 * n * 2 < 2 ** 31
 
 
-def linear(x, weight, bias=None, silu_from_col=None, out=None, _probe_flags=0, residual=None, gate=None):
+LINEAR_WS_FLAG = 0x4000          # zigma_linear_params_t.flags: ZIGMA_LINEAR_WS (csrc/linear_ws.hip)
+
+
+def linear_ws_eligible(x, weight, bias=None):
+    """limits of the weight-stationary kernel (csrc/linear_ws.hip: the W panel of 256 features lives in the registers of a workgroup, only the
+    tokens stream): bf16, no bias, 384 <= k <= 640 in steps of 128, n % 256 == 0 (<= 8192), tokens % 512 == 0, x rows a multiple of 128
+    elements apart — on top of linear_eligible's alignment rules."""
+    if bias is not None or not linear_eligible(x, weight, None, prefer_own=True):
+        return False
+    n, k = weight.shape
+    m = x.numel() // k
+    return k % 128 == 0 and 384 <= k <= 640 and n % 256 == 0 and n <= 8192 and m % 512 == 0 and m // 512 >= 32 // (n // 256) \
+        and x.stride(-2) % 128 == 0
+
+
+def linear(x, weight, bias=None, silu_from_col=None, out=None, _probe_flags=0, residual=None, gate=None, weight_stationary=False):
     """out = x @ weight.T (+ bias); output columns >= silu_from_col (a multiple of 32) leave as silu(.).
     residual (same shape as the result) + gate (batch, n): out = residual + gate[b] * bf16(x @ weight.T + bias) in the kernel's
     epilogue (the gated branch add of the reference's Block, model_zigma.py:447-449); x must then be (batch, rows, k) with
-    rows % 256 == 0."""
+    rows % 256 == 0.  weight_stationary: the csrc/linear_ws.hip kernel (linear_ws_eligible shapes only; fails otherwise)."""
     dev = _lib.require_device(x, weight, bias, out, residual, gate)
     lead, k = x.shape[:-1], x.shape[-1]
     x2 = x.reshape(-1, k)
@@ -64,7 +81,7 @@ def linear(x, weight, bias=None, silu_from_col=None, out=None, _probe_flags=0, r
         out = torch.empty(x2.shape[0], n, device=x.device, dtype=x.dtype)
     o2 = out if out.dim() == 2 else out.view(-1, n)            # a view: the kernel writes through the row pitch
     P = _lib.LinearParams()
-    P.m, P.n, P.k, P.dtype, P.flags = x2.shape[0], n, k, _lib.dtype_id(x), int(_probe_flags) | (0x2000 if FORCE_8W else 0)
+    P.m, P.n, P.k, P.dtype, P.flags = x2.shape[0], n, k, _lib.dtype_id(x), int(_probe_flags) | (LINEAR_WS_FLAG if weight_stationary else (0x2000 if FORCE_8W else 0))
     P.silu_from_col = n if silu_from_col is None else int(silu_from_col)
     P.x_row_stride, P.w_row_stride, P.out_row_stride = x2.stride(0), weight.stride(0), o2.stride(0)
     P.x, P.w, P.bias, P.out = _lib.ptr(x2), _lib.ptr(weight), _lib.ptr(bias), _lib.ptr(o2)

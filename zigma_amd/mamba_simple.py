@@ -15,7 +15,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from .linear import gated_residual_eligible, linear, linear_eligible
+from .linear import gated_residual_eligible, linear, linear_eligible, linear_ws_eligible
 from .selective_scan_interface import mamba_inner_tok
 from .wgrad import linear_train
 
@@ -24,6 +24,7 @@ NO_COPY_TEMPORAL = True      # video "t" layers on strided views (False: the tra
 
 IN_PROJ_SPLIT = os.environ.get("ZIGMA_IN_PROJ_SPLIT", "1") == "1"      # in_proj as two half-width launches of the own kernel
 IN_PROJ_SPLIT_MIN_TOKENS = 32768
+IN_PROJ_WS = os.environ.get("ZIGMA_IN_PROJ_WS", "1") == "1"            # in_proj on the weight-stationary kernel (csrc/linear_ws.hip) where it serves the shape
 
 
 def _int32_table(t, device):
@@ -268,6 +269,9 @@ class Mamba(nn.Module):
         if linear_eligible(x, lin.weight, lin.bias):
             return linear(x, lin.weight, lin.bias)
         n = lin.weight.shape[0]
+        if IN_PROJ_WS and lin.bias is None and x.shape[:-1].numel() >= IN_PROJ_SPLIT_MIN_TOKENS and linear_ws_eligible(x, lin.weight):
+            # ONE launch, W_in panels resident in registers, only the tokens stream (half the L2 -> LDS bytes of the tiled kernel)
+            return linear(x, lin.weight, weight_stationary=True)
         if (IN_PROJ_SPLIT and lin.bias is None and n % 512 == 0 and n >= 2048 and x.dim() == 3
                 and linear_eligible(x, lin.weight[:n // 2], None, prefer_own=True) and x.shape[0] * x.shape[1] >= IN_PROJ_SPLIT_MIN_TOKENS):
             # in_proj as TWO launches of the own 4-wave kernel, one per half of the output columns, into one (B, L, 2 d_inner) buffer:

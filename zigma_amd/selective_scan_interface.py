@@ -254,10 +254,10 @@ DT_PROJ_IN_SCAN = os.environ.get("ZIGMA_DT_IN_SCAN", "1") == "1"     # dt_proj +
 
 
 def dt_in_scan_eligible(u, x_dbl, weight, reset_period=0, out=None):
-    """limits of the in-kernel dt_proj of scan_tok2_kernel (zigma_scan_params_t.dt_x): bf16, whole-sequence mode of the hot kernel
+    """limits of the in-kernel dt_proj of scan_tok2_kernel (zigma_scan_params_t.dt_x): bf16 / fp16, whole-sequence mode of the hot kernel
     (seqlen % 16 == 0, d_inner % 64 == 0, no reset_period), 32 <= dt_rank <= 64 and % 8 == 0, x_dbl rows >= 64 wide, 16-byte aligned rows"""
     R = weight.shape[1]
-    return (u.is_cuda and u.dtype == torch.bfloat16 and x_dbl.dtype == torch.bfloat16 and weight.dtype == torch.bfloat16 and not reset_period
+    return (u.is_cuda and u.dtype in (torch.bfloat16, torch.float16) and x_dbl.dtype == u.dtype and weight.dtype == u.dtype and not reset_period
             and 32 <= R <= 64 and R % 8 == 0 and u.shape[1] % 16 == 0 and u.shape[2] % 64 == 0 and x_dbl.dim() == 3 and x_dbl.shape[2] >= 64
             and x_dbl.stride(2) == 1 and x_dbl.stride(1) % 8 == 0 and x_dbl.stride(0) % 8 == 0 and weight.stride(1) == 1 and weight.stride(0) % 8 == 0
             and x_dbl.data_ptr() % 16 == 0 and weight.data_ptr() % 16 == 0 and u.shape[0] <= 65535)
