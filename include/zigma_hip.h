@@ -487,12 +487,17 @@ int zigma_conv_x_proj_fwd(const zigma_conv_xproj_params_t *p, void *stream);
  * silu_from_col: output columns >= this value leave as silu(value) (in_proj writes silu(z) for the gate half, consumed by
  * the scan under ZIGMA_SCAN_Z_PREACTIVATED); pass n for a plain projection.  Must be a multiple of 32.
  * Limits: bf16; k % 64 == 0; n % 128 == 0; x / w rows 16-byte aligned, out rows 8-byte aligned.
+ * ZIGMA_LINEAR_WS (flags): the weight-stationary kernel (csrc/linear_ws.hip — a 256-feature panel of w lives in the registers of a
+ * workgroup, only the rows of x stream; the in_proj of the default path).  Same result bit for bit.  Limits, else ZIGMA_ERR_UNSUPPORTED:
+ * no bias / activation / residual, k % 128 == 0 and 384 <= k <= 640, n % 256 == 0 and n <= 8192, m % 512 == 0 with m / 512 >= 32 / (n / 256),
+ * x rows a multiple of 128 elements apart, out rows 16-byte aligned.
  * ------------------------------------------------------------------------------------------ */
+#define ZIGMA_LINEAR_WS 0x4000
 typedef struct zigma_linear_params {
     int64_t m;
     int32_t n, k;
     int32_t dtype;           /* ZIGMA_BF16 */
-    int32_t flags;           /* reserved, must be 0 */
+    int32_t flags;           /* 0, or ZIGMA_LINEAR_WS (other bits: probes of tools/, refused by the shipped library) */
     int32_t silu_from_col;
     int32_t pad_;
     int64_t x_row_stride, w_row_stride, out_row_stride;

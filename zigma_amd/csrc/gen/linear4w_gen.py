@@ -107,6 +107,10 @@ def acc(nb, mb):
 # ------------------------------------------------------------------------------------------------------------------
 # emitter with issue log: counted waits are derived from it
 # ------------------------------------------------------------------------------------------------------------------
+# cache policy of the output stores.  nt (streaming; L4W_STORE_NT=1 regenerates the body with it) measured: each of the tiled projections,
+# the attention core and the norm kernels alone -0.4 ... -0.9 % on the forward, all three together +-0 (17.92 vs 17.85 ms, three rounds on one
+# box): not adopted.  Only linear_ws stores nt (stand-alone 203 -> 184 us on the in_proj shape).
+STORE_POLICY = " nt" if os.environ.get("L4W_STORE_NT", "0") == "1" else ""
 OPTS = set()       # probe variants (timing only, results wrong): "nomfma", "noreads", "noglds", "nostore", "laxvm", "noepi"
 CFG = dict(narrow=False, res=False, bias=False)     # what the body being generated supports (see VARIANTS)
 
@@ -214,7 +218,7 @@ class Emit:
     def store(self, data, soff, imm):
         if "nostore" in OPTS:
             return
-        self.ins(f"buffer_store_dwordx4 {v(data, 4)}, {v(RM.STOFF)}, {s(RM.S_RS, 4)}, {s(soff)} offen offset:{imm}")
+        self.ins(f"buffer_store_dwordx4 {v(data, 4)}, {v(RM.STOFF)}, {s(RM.S_RS, 4)}, {s(soff)} offen offset:{imm}{STORE_POLICY}")
         self._vm()
 
     def res_load(self, dst, soff, imm):

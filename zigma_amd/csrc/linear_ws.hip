@@ -30,6 +30,11 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 typedef __attribute__((address_space(3))) unsigned char *lds_ptr_t;
 
+#ifdef ZIGMA_WS_NO_NT
+constexpr bool kWsDefaultPolicyStores = true;     // (A/B build of tools/fwd_nt_ab.sh)
+#else
+constexpr bool kWsDefaultPolicyStores = false;
+#endif
 constexpr int kT = 64;                    // tokens per tile
 constexpr int kSlice = kT * 256;          // ring slot: 64 tokens x 128 k, bf16
 constexpr int kRing = 8;
@@ -79,7 +84,7 @@ __device__ __forceinline__ void mfma_f(f32x16 &acc, const WFrags<KG> &w, const i
 }
 
 // PROBE (tools/linear_ws_probe.py; probe builds only): 0 = the kernel, 1 = no epilogue, 2 = default-policy stores instead of nt,
-// 3 = MFMAs only (no stream after the prologue, no barriers, no fragment reads, no epilogue), 4 = sc0 sc1 (write-through) stores, 5 = no fragment reads (wrong results), 6 = the epilogue without its global stores, 7 = every tile stored over the workgroup's first tile (wrong results)
+// 3 = MFMAs only (no stream after the prologue, no barriers, no fragment reads, no epilogue), 4 = sc0 sc1 (write-through) stores, 5 = no fragment reads (wrong results), 6 = the epilogue without its global stores, 7 = one barrier per slice instead of one per two
 template <int KG, int PROBE>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
 void linear_ws_kernel(const zigma_linear_params_t p, const int panels, const int ranges, const int tiles_per_xcd) {
@@ -149,7 +154,7 @@ void linear_ws_kernel(const zigma_linear_params_t p, const int panels, const int
     unsigned char *ob = reinterpret_cast<unsigned char *>(p.out) + static_cast<int64_t>(t_lo) * kT * o_pitch +
                         (static_cast<int64_t>(panel) * 256 + wave * 64) * 2;    // (wave-uniform)
 
-    wait_vm<4 * (kRing - 2)>();                          // slice 0 landed (this wave's part) — hipcc has drained everything for the weights anyway
+    wait_vm<4 * (kRing - 3)>();                          // slices 0 and 1 landed (this wave's part) — hipcc has drained everything for the weights anyway
     barrier();
     u32x4 bf[2][2];
     lds_rd<0>(bf[0][0], a_off);
@@ -159,14 +164,25 @@ void linear_ws_kernel(const zigma_linear_params_t p, const int panels, const int
     // store instruction = 8 tokens x 128 B); k-group qg of the NEXT tile carries write chunks (qg - W0) WP .. and read chunk qg - R0
     constexpr int WP = KG >= 32 ? 1 : 2, W0 = 1, R0 = W0 + 16 / WP + (KG >= 32 ? 2 : 0);
     static_assert(R0 + 9 <= KG, "the epilogue has to fit the k-loop");
-    auto wr_chunk = [&](f32x16 (&pa)[4], const int c, const unsigned sw) {             // c = 8 tb + 4 fb + q4
+    // a write chunk in two halves so that each fits one MFMA gap (a gap hides about five single-issue instructions):
+    //   rd: four accumulator registers -> VGPRs;   wr: 2 x v_cvt_pk_bf16_f32, address, ds_write_b64
+    auto wr_chunk_rd = [&](f32x16 (&pa)[4], const int c, float (&d)[4]) {      // c = 8 tb + 4 fb + q4
+        const int b = 2 * (c >> 3) + ((c >> 2) & 1), q4 = c & 3;
+        asm volatile("" : "+a"(pa[b]));                             // (pins the four register reads below behind this point of the asm stream)
+        d[0] = pa[b][4 * q4]; d[1] = pa[b][4 * q4 + 1]; d[2] = pa[b][4 * q4 + 2]; d[3] = pa[b][4 * q4 + 3];
+        asm volatile("" : "+v"(d[0]), "+v"(d[1]), "+v"(d[2]), "+v"(d[3]));     // (... and in front of this one)
+    };
+    auto wr_chunk_wr = [&](const int c, const float (&d)[4], const unsigned sw) {
         const int tb = c >> 3, fb = (c >> 2) & 1, q4 = c & 3;
-        asm volatile("" : "+a"(pa[2 * tb + fb]));                  // (pins the four register reads below behind this point of the asm stream)
-        const float d0 = pa[2 * tb + fb][4 * q4], d1 = pa[2 * tb + fb][4 * q4 + 1], d2 = pa[2 * tb + fb][4 * q4 + 2], d3 = pa[2 * tb + fb][4 * q4 + 3];
-        const u32x2 pk = {pack_bf2(d0, d1), pack_bf2(d2, d3)};
+        const u32x2 pk = {pack_bf2(d[0], d[1]), pack_bf2(d[2], d[3])};
         const unsigned addr = sw + (static_cast<unsigned>((fb * 4 + q4) << 4) ^ sw_w);
         if (tb == 0) asm volatile("ds_write_b64 %0, %1" ::"v"(addr), "v"(pk) : "memory");
         else asm volatile("ds_write_b64 %0, %1 offset:4096" ::"v"(addr), "v"(pk) : "memory");
+    };
+    auto wr_chunk = [&](f32x16 (&pa)[4], const int c, const unsigned sw) {
+        float d[4];
+        wr_chunk_rd(pa, c, d);
+        wr_chunk_wr(c, d, sw);
     };
     auto rd_chunk = [&](u32x4 &o, const int r, const unsigned sr) {                    // r = 4 tb + i: tokens 32 tb + 8 i + tr
         const unsigned addr = (r & 1) ? sr ^ 64u : sr;   // rows 8 r + tr -> byte offset 1024 r
@@ -184,7 +200,7 @@ void linear_ws_kernel(const zigma_linear_params_t p, const int panels, const int
     auto tile = [&](auto par_c, auto epi_c, const int t) {
         constexpr int PAR = decltype(par_c)::value;
         constexpr bool EPI = decltype(epi_c)::value && PROBE != 1 && PROBE != 3;
-        unsigned char *ot = ob + static_cast<int64_t>(PROBE == 7 ? 0 : t - 1) * kT * o_pitch;       // rows of the PREVIOUS tile
+        unsigned char *ot = ob + static_cast<int64_t>(t - 1) * kT * o_pitch;       // rows of the PREVIOUS tile
         u32x4 o;
         // per-tile opaque copies of the three address bases: everything derived from them is computed where it is used (hoisted out of the
         // tile loop by hipcc, the 8 + 8 + 2 derived addresses cost the registers that make the k = 640 kernel spill)
@@ -199,9 +215,11 @@ void linear_ws_kernel(const zigma_linear_params_t p, const int panels, const int
                 // One k-group = 4 MFMAs with everything else in the three gaps between them and behind the last one (with a single wave
                 // per SIMD whatever sits in FRONT of the first MFMA runs with the matrix pipe idle):
                 //   top    the fragments of this group have landed: lgkmcnt(number of LDS instructions issued behind their reads)
-                //   gap A  store of the epilogue piece read one group ago, read-back of the next piece, fragment reads of the next group
-                //   gap B  two of the slice's four direct-to-LDS loads (k-group 6 only)
-                //   gap C  epilogue write chunk (4 accumulator registers -> bf16 -> LDS), third load
+                //   front  fragment reads of the NEXT group
+                //   gap A  store of the epilogue piece read one group ago, read-back of the next piece
+                //   gap B  epilogue write chunk, first half (4 accumulator registers -> VGPRs); two of the slice's four direct-to-LDS loads
+                //          (k-group 6 only)
+                //   gap C  second half (-> bf16 -> LDS), third load
                 //   gap D  fourth load, second write chunk (k = 512)
                 const int qg = ks * 8 + q, r = qg - R0;
                 const int c0 = (qg - W0) * WP;                                  // write chunks of this group: c0 .. c0 + WP - 1 where in [0, 16)
@@ -209,30 +227,26 @@ void linear_ws_kernel(const zigma_linear_params_t p, const int panels, const int
                 int nw_prev = 0;
 #pragma unroll
                 for (int c = cp; c < cp + WP; ++c) nw_prev += (EPI && qg > 0 && c >= 0 && c < 16) ? 1 : 0;
-                if (q == 6) {                            // slice g + 1: landed everywhere; slot of slice g - 1 is free -> slice g + 7
-                    wait_vm<4 * (kRing - 3)>();
+                // ONE workgroup barrier per TWO slices (PROBE 7: per slice, the first form): in k-group 6 of every odd slice g the slices g + 1 and
+                // g + 2 have landed everywhere (each wave has waited for its own parts) and the slots of g - 2 and g - 1 are free for g + 6, g + 7
+                const bool two = PROBE != 7;
+                const bool sync = two ? (((NS & 1) * PAR + ks) & 1) == 1 : true;         // g = NS t + ks: its parity is known at compile time
+                if (q == 6 && sync) {
+                    if (two) wait_vm<4 * (kRing - 5)>(); else wait_vm<4 * (kRing - 3)>();
                     if (PROBE != 3) barrier();
                 }
+                const bool rd_prev = EPI && r - 1 >= 0 && r - 1 < 8;             // a read-back chunk was issued in gap A of the previous group
+                const int n_top = nw_prev + (rd_prev ? 1 : 0);
                 if (PROBE == 5 || PROBE == 3) wait_lgkm<0>();
-                else if (nw_prev == 0) wait_lgkm<0>();
-                else if (nw_prev == 1) wait_lgkm<1>();
-                else wait_lgkm<2>();
+                else if (n_top == 0) wait_lgkm<0>();
+                else if (n_top == 1) wait_lgkm<1>();
+                else if (n_top == 2) wait_lgkm<2>();
+                else wait_lgkm<3>();
                 const bool first = qg == 0;
-                const int t7 = t + (ks + 7) / NS, ks7 = (ks + 7) % NS;
-                const bool dma = q == 6 && PROBE != 3;
-                mfma_f<KG>(acc[PAR][0], w, 2 * qg, first, bf[q & 1][0]);
-                // ---- gap A
-                if (EPI && r - 1 >= 0 && r - 1 < 8 && PROBE != 6) {
-                    const unsigned char *dst = ot + 8 * (r - 1) * o_pitch;      // (wave-uniform: SGPR base + 32-bit lane offset)
-                    // (s_nop: a store of more than 8 bytes must not be followed directly by a write of its data registers — hipcc pads its
-                    // own stores, it does not see this one; without it the first dword of four lanes in sixteen went out overwritten)
-                    // nt: the 335 MB of an in_proj output do not belong in the L2 next to the activation slices (184 vs 203 us with the default policy)
-                    if (PROBE == 2) asm volatile("global_store_dwordx4 %0, %1, %2\n\ts_nop 1" ::"v"(lane_out), "v"(o), "s"(dst) : "memory");
-                    else if (PROBE == 4) asm volatile("global_store_dwordx4 %0, %1, %2 sc0 sc1\n\ts_nop 1" ::"v"(lane_out), "v"(o), "s"(dst) : "memory");
-                    else asm volatile("global_store_dwordx4 %0, %1, %2 nt\n\ts_nop 1" ::"v"(lane_out), "v"(o), "s"(dst) : "memory");
-                }
-                if (EPI && r >= 0 && r < 8) rd_chunk(o, r, sr);
-                if (PROBE == 5 || PROBE == 3) {
+                // the direct-to-LDS loads behind a barrier: slice g + 6 in the gaps of k-group 6, slice g + 7 in those of k-group 7 (per-slice form: g + 7 in 6)
+                const bool dma = PROBE != 3 && sync && (q == 6 || (two && q == 7));
+                const int dd = two ? q : 7;                                      // slice g + dd
+                if (PROBE == 5 || PROBE == 3) {          // the fragments of the NEXT group: a full group (4 MFMAs) of latency cover
                 } else if (q < 7) {
                     const unsigned ad = (ao ^ ((q + 1) << 5)) + sb;
                     lds_rd<0>(bf[(q + 1) & 1][0], ad);
@@ -242,16 +256,33 @@ void linear_ws_kernel(const zigma_linear_params_t p, const int panels, const int
                     lds_rd<0>(bf[0][0], ad);
                     lds_rd<8192>(bf[0][1], ad);
                 }
+                mfma_f<KG>(acc[PAR][0], w, 2 * qg, first, bf[q & 1][0]);
+                // ---- gap A
+                if (rd_prev && PROBE != 6) {
+                    const unsigned char *dst = ot + 8 * (r - 1) * o_pitch;      // (wave-uniform: SGPR base + 32-bit lane offset)
+                    // the chunk read one group ago has landed: behind it in the LDS queue sit that group's write chunk(s) and the two fragment reads above
+                    if (nw_prev == 0) wait_lgkm<2>(); else if (nw_prev == 1) wait_lgkm<3>(); else wait_lgkm<4>();
+                    // (s_nop: a store of more than 8 bytes must not be followed directly by a write of its data registers — hipcc pads its
+                    // own stores, it does not see this one; without it the first dword of four lanes in sixteen went out overwritten)
+                    // nt: the 335 MB of an in_proj output do not belong in the L2 next to the activation slices (184 vs 203 us with the default policy)
+                    if (PROBE == 2 || kWsDefaultPolicyStores) asm volatile("global_store_dwordx4 %0, %1, %2\n\ts_nop 1" ::"v"(lane_out), "v"(o), "s"(dst) : "memory");
+                    else if (PROBE == 4) asm volatile("global_store_dwordx4 %0, %1, %2 sc0 sc1\n\ts_nop 1" ::"v"(lane_out), "v"(o), "s"(dst) : "memory");
+                    else asm volatile("global_store_dwordx4 %0, %1, %2 nt\n\ts_nop 1" ::"v"(lane_out), "v"(o), "s"(dst) : "memory");
+                }
+                if (EPI && r >= 0 && r < 8) rd_chunk(o, r, sr);
                 mfma_f<KG>(acc[PAR][1], w, 2 * qg + 1, first, bf[q & 1][0]);
                 // ---- gap B
-                if (dma) { issue_one(t7, ks7, g + 7, 0); issue_one(t7, ks7, g + 7, 1); }
+                float dch[4];
+                const bool chunk = EPI && c0 >= 0 && c0 < 16;
+                if (chunk) wr_chunk_rd(acc[PAR ^ 1], c0, dch);
+                if (dma) { issue_one(t + (ks + dd) / NS, (ks + dd) % NS, g + dd, 0); issue_one(t + (ks + dd) / NS, (ks + dd) % NS, g + dd, 1); }
                 mfma_f<KG>(acc[PAR][2], w, 2 * qg, first, bf[q & 1][1]);
                 // ---- gap C
-                if (EPI && c0 >= 0 && c0 < 16) wr_chunk(acc[PAR ^ 1], c0, sw);
-                if (dma) issue_one(t7, ks7, g + 7, 2);
+                if (chunk) wr_chunk_wr(c0, dch, sw);
+                if (dma) issue_one(t + (ks + dd) / NS, (ks + dd) % NS, g + dd, 2);
                 mfma_f<KG>(acc[PAR][3], w, 2 * qg + 1, first, bf[q & 1][1]);
                 // ---- gap D
-                if (dma) issue_one(t7, ks7, g + 7, 3);
+                if (dma) issue_one(t + (ks + dd) / NS, (ks + dd) % NS, g + dd, 3);
                 if (EPI && WP == 2 && c0 + 1 >= 0 && c0 + 1 < 16) wr_chunk(acc[PAR ^ 1], c0 + 1, sw);
             }
         }
