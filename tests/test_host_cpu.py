@@ -68,6 +68,25 @@ def test_ctypes_structs_match_the_header():
             assert int(got[f"{cname}.{f}"]) == getattr(st, f).offset, (cname, f)
 
 
+def test_flag_constants_match_the_header():
+    """the Python mirrors of the header's flag / kernel-id constants (a drifted copy would select another kernel silently)"""
+    import re
+    from zigma_amd import _lib
+    import zigma_amd.linear as zl
+    hdr = open(os.path.join(ROOT, "include", "zigma_hip.h")).read()
+    defs = {m.group(1): int(m.group(2), 0) for m in re.finditer(r"#define\s+(ZIGMA_\w+)\s+(0x[0-9a-fA-F]+|\d+)\b", hdr)}
+    assert defs["ZIGMA_LINEAR_WS"] == zl.LINEAR_WS_FLAG
+    assert defs["ZIGMA_SCAN_KERNEL_TOK2"] == _lib.SCAN_KERNEL_TOK2
+    assert defs["ZIGMA_ABI_VERSION"] == 9
+
+
+def test_linear_ws_policy_limits_on_cpu_tensors():
+    """linear_ws_eligible never claims a CPU tensor or a shape outside the kernel's limits (the C side re-checks and refuses)"""
+    from zigma_amd.linear import linear_ws_eligible
+    x = torch.zeros(4096, 640, dtype=torch.bfloat16)
+    assert not linear_ws_eligible(x, torch.zeros(2560, 640, dtype=torch.bfloat16))          # not on the device
+
+
 def test_scan_paths_bit_exact_vs_reference_tables():
     from zigma_amd import scan_paths as sp
     g = load_golden("paths.npz")

@@ -331,7 +331,7 @@ bool linear_ws_eligible(const zigma_linear_params_t &p) {
     const int panels = p.n / 256, ranges = 32 / panels;
     const int64_t tiles_per_xcd = p.m / 512;
     if (tiles_per_xcd < ranges || tiles_per_xcd > 0x7fffff) return false;
-    if (p.m * p.out_row_stride * 2 > 0x7fffffffffll) return false;
+    if (p.out_row_stride * 2 * 8 > 0x7fffffff) return false;      // 32-bit lane offset of a store (8 rows)
     return p.x_row_stride % 128 == 0 && 64 * p.x_row_stride * 2 < 0x7fffffff;          // (slot swizzle in the low byte of the lane offset; 32-bit offsets inside a slice)
 }
 
