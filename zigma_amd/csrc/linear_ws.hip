@@ -84,7 +84,7 @@ __device__ __forceinline__ void mfma_f(f32x16 &acc, const WFrags<KG> &w, const i
 }
 
 // PROBE (tools/linear_ws_probe.py; probe builds only): 0 = the kernel, 1 = no epilogue, 2 = default-policy stores instead of nt,
-// 3 = MFMAs only (no stream after the prologue, no barriers, no fragment reads, no epilogue), 4 = sc0 sc1 (write-through) stores, 5 = no fragment reads (wrong results), 6 = the epilogue without its global stores, 7 = one barrier per slice instead of one per two
+// 3 = MFMAs only (no stream after the prologue, no barriers, no fragment reads, no epilogue), 4 = sc0 sc1 (write-through) stores, 5 = no fragment reads (wrong results), 6 = only the MFMAs of feature block 0 (one MFMA per fragment read: the loop rate of a 128-feature panel; wrong results), 7 = one barrier per slice instead of one per two
 template <int KG, int PROBE>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
 void linear_ws_kernel(const zigma_linear_params_t p, const int panels, const int ranges, const int tiles_per_xcd) {
@@ -258,7 +258,7 @@ void linear_ws_kernel(const zigma_linear_params_t p, const int panels, const int
                 }
                 mfma_f<KG>(acc[PAR][0], w, 2 * qg, first, bf[q & 1][0]);
                 // ---- gap A
-                if (rd_prev && PROBE != 6) {
+                if (rd_prev) {
                     const unsigned char *dst = ot + 8 * (r - 1) * o_pitch;      // (wave-uniform: SGPR base + 32-bit lane offset)
                     // the chunk read one group ago has landed: behind it in the LDS queue sit that group's write chunk(s) and the two fragment reads above
                     if (nw_prev == 0) wait_lgkm<2>(); else if (nw_prev == 1) wait_lgkm<3>(); else wait_lgkm<4>();
@@ -270,7 +270,7 @@ void linear_ws_kernel(const zigma_linear_params_t p, const int panels, const int
                     else asm volatile("global_store_dwordx4 %0, %1, %2 nt\n\ts_nop 1" ::"v"(lane_out), "v"(o), "s"(dst) : "memory");
                 }
                 if (EPI && r >= 0 && r < 8) rd_chunk(o, r, sr);
-                mfma_f<KG>(acc[PAR][1], w, 2 * qg + 1, first, bf[q & 1][0]);
+                if (PROBE != 6) mfma_f<KG>(acc[PAR][1], w, 2 * qg + 1, first, bf[q & 1][0]);
                 // ---- gap B
                 float dch[4];
                 const bool chunk = EPI && c0 >= 0 && c0 < 16;
@@ -280,7 +280,7 @@ void linear_ws_kernel(const zigma_linear_params_t p, const int panels, const int
                 // ---- gap C
                 if (chunk) wr_chunk_wr(c0, dch, sw);
                 if (dma) issue_one(t + (ks + dd) / NS, (ks + dd) % NS, g + dd, 2);
-                mfma_f<KG>(acc[PAR][3], w, 2 * qg + 1, first, bf[q & 1][1]);
+                if (PROBE != 6) mfma_f<KG>(acc[PAR][3], w, 2 * qg + 1, first, bf[q & 1][1]);
                 // ---- gap D
                 if (dma) issue_one(t + (ks + dd) / NS, (ks + dd) % NS, g + dd, 3);
                 if (EPI && WP == 2 && c0 + 1 >= 0 && c0 + 1 < 16) wr_chunk(acc[PAR ^ 1], c0 + 1, sw);

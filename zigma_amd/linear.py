@@ -1,6 +1,7 @@
 """Dense projections on the hand-written MFMA kernel (zigma_linear_fwd): in_proj / out_proj of the Mamba mixer and
 to_q / to_out of the cross-attention (reference call sites mamba_simple.py:290-294, selective_scan_interface.py:365,
-model_zigma.py:104-135, all `F.linear`).  Inference path only: when autograd is recording the callers keep F.linear."""
+model_zigma.py:104-135, all `F.linear`).  Under autograd the callers go through wgrad.LinearTrainFn, whose forward product and dX use the same kernels (its own eligibility
+check runs with autograd off); linear_eligible itself refuses tensors that require grad."""
 import torch
 
 from . import _lib

@@ -5,11 +5,29 @@ The reference leaves these to autograd's linear backward (one GEMM each); as ONE
 CUs and run at 0.03 ... 0.5 PFLOP/s (tools/wgrad_split_probe.py: in_proj 450 us, to_q 259 us, x_proj 227 us).  Split along the tokens
 into S slabs as a BATCHED GEMM (the slab index is the library's batch dimension) the same products fill the chip; the S partial
 results (bf16, like a GEMM output) are added in fp32: in_proj 332 us, out_proj 303 -> 149, to_q 259 -> 76, to_out 271 -> 66,
-x_proj 227 -> 72, dt_proj 205 -> 64 us — 17 ms of a 122 ms training step.  `LinearTrainFn` is F.linear with that backward."""
+x_proj 227 -> 72, dt_proj 205 -> 64 us — 17 ms of a 122 ms training step.  `LinearTrainFn` is F.linear with that backward; since round 4 its forward product and dX run on the hand-written projection kernels
+(zigma_linear_fwd) where one serves the shape — `OWN_TRAIN_GEMMS`."""
 import torch
 import torch.nn.functional as F
 
+import os
+
 SPLIT_WGRAD = True        # False: one GEMM (A/B in tools/train_probe.py)
+# forward projection and dX = dY W of the training path on the hand-written MFMA kernels (zigma_linear_fwd: weight-stationary / tiled) where they
+# serve the shape; dW stays the slab-wise batched product below.  "0": the library for both (A/B in tools/train_probe.py)
+OWN_TRAIN_GEMMS = os.environ.get("ZIGMA_TRAIN_OWN_GEMMS", "1") == "1"
+
+
+def _own_linear(x, weight, bias=None):
+    """x @ weight^T (+ bias) on zigma_linear_fwd if a kernel of it serves the call (autograd is off in here), else None"""
+    from .linear import linear, linear_eligible, linear_ws_eligible
+    if not OWN_TRAIN_GEMMS or not x.is_cuda or x.dtype != torch.bfloat16:
+        return None
+    if bias is None and linear_ws_eligible(x, weight):
+        return linear(x, weight, weight_stationary=True)
+    if linear_eligible(x, weight, bias, prefer_own=True):
+        return linear(x, weight, bias)
+    return None
 
 
 def _slabs(m, n, k):
@@ -47,7 +65,8 @@ class LinearTrainFn(torch.autograd.Function):
     def forward(ctx, x, weight, bias):
         ctx.save_for_backward(x, weight)
         ctx.has_bias = bias is not None
-        return F.linear(x, weight, bias)
+        out = _own_linear(x, weight, bias)
+        return F.linear(x, weight, bias) if out is None else out
 
     @staticmethod
     def backward(ctx, dy):
@@ -55,7 +74,9 @@ class LinearTrainFn(torch.autograd.Function):
         dy2 = dy.reshape(-1, dy.shape[-1])
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
-            dx = (dy2 @ weight).view(x.shape)
+            dyc = dy2 if dy2.is_contiguous() else dy2.contiguous()
+            dx = _own_linear(dyc, weight.t().contiguous())         # dX = dY W = dY (W^T)^T: the same kernels on the transposed weight (a few MB)
+            dx = (dy2 @ weight).view(x.shape) if dx is None else dx.view(x.shape)
         if ctx.needs_input_grad[1]:
             dw = wgrad(dy2, x.reshape(-1, x.shape[-1]))
         if ctx.has_bias and ctx.needs_input_grad[2]:
