@@ -489,7 +489,7 @@ int zigma_conv_x_proj_fwd(const zigma_conv_xproj_params_t *p, void *stream);
  * Limits: bf16; k % 64 == 0; n % 128 == 0; x / w rows 16-byte aligned, out rows 8-byte aligned.
  * ZIGMA_LINEAR_WS (flags): the weight-stationary kernel (csrc/linear_ws.hip — a 256-feature panel of w lives in the registers of a
  * workgroup, only the rows of x stream; the in_proj of the default path).  Same result bit for bit.  Limits, else ZIGMA_ERR_UNSUPPORTED:
- * no bias / activation / residual, k % 128 == 0 and 384 <= k <= 640, n % 256 == 0 and n <= 8192, m % 512 == 0 with m / 512 >= 32 / (n / 256),
+ * no bias / activation / residual, k = 512 or 640, n % 256 == 0 and n <= 8192, m % 512 == 0 with m / 512 >= 32 / (n / 256),
  * x rows a multiple of 128 elements apart, out rows 16-byte aligned.
  * ------------------------------------------------------------------------------------------ */
 #define ZIGMA_LINEAR_WS 0x4000

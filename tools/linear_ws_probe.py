@@ -30,7 +30,7 @@ def timed(fn, n=10):
     return e0.elapsed_time(e1) / n * 1e3
 
 
-for name, K, N in (("in_proj", 640, 2560),):
+for name, K, N in (("in_proj", 640, 2560), ("to_q", 640, 512), ("k512_n1024", 512, 1024)):
     x = torch.randn(M, K, device=dev, dtype=dt)
     w = (torch.randn(N, K, device=dev) * K ** -0.5).to(dt)
     y4 = linear(x, w)
@@ -61,7 +61,7 @@ for name, K, N in (("in_proj", 640, 2560),):
     rec["us"] = {k: sorted(v)[len(v) // 2] for k, v in t.items()}
     rec["us_min"] = {k: min(v) for k, v in t.items()}
     rec["probes_us"] = {pn: sorted(timed(lambda: linear(x, w, _probe_flags=0x4000 | fl)) for _ in range(3))[1]
-                        for pn, fl in (("no_epilogue", 0x10000), ("default_policy_stores", 0x20000), ("mfma_only", 0x30000), ("sc0sc1_stores", 0x40000), ("no_frag_reads", 0x50000), ("one_mfma_per_read", 0x60000), ("barrier_per_slice", 0x70000))}
+                        for pn, fl in (("no_epilogue", 0x10000), ("default_policy_stores", 0x20000), ("mfma_only", 0x30000))}
     fl = 2.0 * M * K * N
     rec["PFLOPs"] = {k: fl / (v * 1e-6) / 1e15 for k, v in rec["us"].items()}
     print(json.dumps(rec), flush=True)
