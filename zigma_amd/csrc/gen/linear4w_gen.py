@@ -107,10 +107,11 @@ def acc(nb, mb):
 # ------------------------------------------------------------------------------------------------------------------
 # emitter with issue log: counted waits are derived from it
 # ------------------------------------------------------------------------------------------------------------------
-# cache policy of the output stores.  nt (streaming; L4W_STORE_NT=1 regenerates the body with it) measured: each of the tiled projections,
-# the attention core and the norm kernels alone -0.4 ... -0.9 % on the forward, all three together +-0 (17.92 vs 17.85 ms, three rounds on one
-# box): not adopted.  Only linear_ws stores nt (stand-alone 203 -> 184 us on the in_proj shape).
-STORE_POLICY = " nt" if os.environ.get("L4W_STORE_NT", "0") == "1" else ""
+# cache policy of the output stores: nt (streaming).  Measured inside the forward (tools/fwd_l4w_nt_ab.sh, four interleaved rounds on one
+# box): 18.04 / 18.09 / 18.13 / 18.15 ms with the default policy against 17.98 / 18.04 / 18.07 / 18.11 with nt (-0.3 %, every round).  The same
+# switch on the attention core and the norm kernels: +-0 together with this one; on the scan's output +-0, on conv + x_proj's +0.8 %: not
+# adopted there.  L4W_STORE_NT=0 regenerates the default-policy body for that A/B.
+STORE_POLICY = " nt" if os.environ.get("L4W_STORE_NT", "1") == "1" else ""
 OPTS = set()       # probe variants (timing only, results wrong): "nomfma", "noreads", "noglds", "nostore", "laxvm", "noepi"
 CFG = dict(narrow=False, res=False, bias=False)     # what the body being generated supports (see VARIANTS)
 
