@@ -112,6 +112,7 @@ def acc(nb, mb):
 # switch on the attention core and the norm kernels: +-0 together with this one; on the scan's output +-0, on conv + x_proj's +0.8 %: not
 # adopted there.  L4W_STORE_NT=0 regenerates the default-policy body for that A/B.
 STORE_POLICY = " nt" if os.environ.get("L4W_STORE_NT", "1") == "1" else ""
+RES_AHEAD = os.environ.get("L4W_RES_AHEAD", "1") == "1"      # residual rows of the next block pair requested in front of this pair's stores
 OPTS = set()       # probe variants (timing only, results wrong): "nomfma", "noreads", "noglds", "nostore", "laxvm", "noepi"
 CFG = dict(narrow=False, res=False, bias=False)     # what the body being generated supports (see VARIANTS)
 
@@ -504,6 +505,7 @@ def step_last(e, p, uid, nbw=4):
     # every remaining fragment read of this stage goes out before the boundary
     rest = (rd_a(1) if nbps == 2 else []) + rd_b(1) + rd_b(2) + rd_b(3)
     per = (len(rest) + bpos - 1) // bpos
+    res_sets = {}                                       # pair index -> registers holding its residual rows, requested a pair ahead
     for sl, (mb, nbp) in enumerate(pairs):
         fill = []
         if sl < bpos:
@@ -512,9 +514,22 @@ def step_last(e, p, uid, nbw=4):
             fill += cursor_advance(e, uid)              # (pending from the batch the step before issued)
         if sl >= 1:
             pmb, pnbp = pairs[sl - 1]
-            # B fragments of token block 0 are dead once its pairs have issued: their 16 registers take the pair's residual rows
-            res16 = last_LB(0, 0) if (CFG["res"] and mb >= 1) else None
-            fill += (residual_loads(e, pnbp, pmb, res16) if res16 is not None else []) + epilogue_E1(e, pnbp, pmb) + epilogue_rows(e, pnbp, pmb, res16)
+            # B fragments of token block 0 are dead once its pairs have issued: their 16 registers take the pair's residual rows.  Once
+            # token block 1 is done too there are TWO such sets: from then on the rows of the NEXT pair are requested here as well, in FRONT
+            # of this pair's stores — a load behind a store is usable only once memory has acknowledged that store (the counter retires in
+            # issue order), so without the second set every pair starts by waiting out the stores of the pair before
+            res16, loads = None, []
+            if CFG["res"] and mb >= 1:
+                if (sl - 1) in res_sets:
+                    res16 = res_sets[sl - 1]                                  # requested one pair ago
+                else:
+                    res16 = last_LB(0, 0)
+                    loads = residual_loads(e, pnbp, pmb, res16)
+                if RES_AHEAD and mb >= 2:
+                    nxt = last_LB(1, 0) if res16 == last_LB(0, 0) else last_LB(0, 0)
+                    res_sets[sl] = nxt
+                    loads = loads + residual_loads(e, nbp, mb, nxt)          # (the pair this step computes: its epilogue runs in the next step)
+            fill += loads + epilogue_E1(e, pnbp, pmb) + epilogue_rows(e, pnbp, pmb, res16)
         if sl == bpos:
             e.ins(f"s_waitcnt vmcnt({e.vm_own}) lgkmcnt(0)")      # (everything of mine so far is younger than the awaited batch)
             e.lgkm, e.vmq = [], []
@@ -536,8 +551,9 @@ def step_last(e, p, uid, nbw=4):
                 mf.append(lambda ks=ks, nbl=nbl: e.mfma(acc(2 * nbp + nbl, mb), LA(nbp, nbl, ks), LB(mb, ks)))
         interleave(e, mf, fill, first_gap=1 if sl >= 1 else 0)
     pmb, pnbp = pairs[-1]
-    res16 = last_LB(0, 0) if CFG["res"] else None
-    for f in (residual_loads(e, pnbp, pmb, res16) if res16 is not None else []) + epilogue_E1(e, pnbp, pmb) + epilogue_rows(e, pnbp, pmb, res16):
+    res16 = (res_sets.get(len(pairs) - 1) or last_LB(0, 0)) if CFG["res"] else None
+    tail_loads = residual_loads(e, pnbp, pmb, res16) if (res16 is not None and (len(pairs) - 1) not in res_sets) else []
+    for f in tail_loads + epilogue_E1(e, pnbp, pmb) + epilogue_rows(e, pnbp, pmb, res16):
         f()
     return e.vm_after_glds
 
