@@ -17,6 +17,14 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=f
          "-I" + os.path.join(ROOT, "include"), "-I" + CSRC]
 
 
+# per-source flags.  cross_attn.hip: MFMA results in VGPRs — its accumulators are consumed by VALU code right away (softmax, normalisation);
+# left to the default (AGPR destinations in a kernel with registers to spare) every result costs a v_accvgpr_read_b32
+# (the same switch on conv_x_proj.hip and cross_attn_bwd.hip removes their AGPR moves too and changes nothing measurable: 17.21-17.28 vs
+# 17.23-17.26 ms per forward, 97.5-98.2 vs 96.8-98.0 ms per training step, tools/fwd_vgpr_mfma_ab.sh)
+_VGPR_MFMA = ["-mllvm", "-amdgpu-mfma-vgpr-form=1"]
+SOURCE_FLAGS = {"cross_attn.hip": _VGPR_MFMA}
+
+
 def _digest(paths, extra=()):
     h = hashlib.sha256()
     for pth in sorted(paths):
@@ -39,7 +47,7 @@ def build(force=False, verbose=True, sources=None, lib=None, extra_flags=()):
     headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".h", ".inc"))]
     headers.append(os.path.join(ROOT, "include", "zigma_hip.h"))
     stamp = lib + ".srchash"
-    want = _digest([os.path.join(CSRC, s) for s in sources] + headers, extra=list(FLAGS) + list(extra_flags))
+    want = _digest([os.path.join(CSRC, s) for s in sources] + headers, extra=list(FLAGS) + list(extra_flags) + [str(sorted(SOURCE_FLAGS.items()))])
     if not force and os.path.exists(lib) and os.path.exists(stamp) and open(stamp).read().strip() == want:
         if verbose:
             print(f"{lib} is up to date (source hash {want[:12]})")
@@ -55,10 +63,11 @@ def build(force=False, verbose=True, sources=None, lib=None, extra_flags=()):
         s_path = os.path.join(CSRC, src)
         o_path = os.path.join(obj_dir, src.replace(".hip", ".o"))
         o_stamp = o_path + ".srchash"
-        o_want = _digest([s_path] + headers, extra=list(FLAGS) + list(extra_flags))
+        src_flags = SOURCE_FLAGS.get(src, [])
+        o_want = _digest([s_path] + headers, extra=list(FLAGS) + list(extra_flags) + src_flags)
         objs.append(o_path)
         if force or not os.path.exists(o_path) or not os.path.exists(o_stamp) or open(o_stamp).read().strip() != o_want:
-            jobs.append(([HIPCC, *FLAGS, *extra_flags, "-c", s_path, "-o", o_path], o_stamp, o_want))
+            jobs.append(([HIPCC, *FLAGS, *extra_flags, *src_flags, "-c", s_path, "-o", o_path], o_stamp, o_want))
 
     def compile_one(job):
         cmd, o_stamp, o_want = job

@@ -27,11 +27,14 @@ constexpr int kXaKPitch = (kXaD + 8) * 2;   // bytes per K row in LDS (16 B skew
 // 16-token tiles per wave = how many query tokens share one staging of K_h / V_h^T (20 KB): 8 (512 tokens per workgroup) where the
 // sequence has them — 35.5 us against 38.0 with 4 and 40.2 with 16 at the headline shape (tools/attn_probe.py) —, 4 for short ones
 
-__device__ __forceinline__ uint32_t pack_bf16(float lo, float hi) {
-    return static_cast<uint32_t>(from_float<BF16>(lo)) | (static_cast<uint32_t>(from_float<BF16>(hi)) << 16);
+typedef float xa_f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 xa_bf16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t pack_bf16(float lo, float hi) {        // one v_cvt_pk_bf16_f32 (round to nearest even, like from_float<BF16>)
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(xa_f32x2{lo, hi}, xa_bf16x2));
 }
 
-template <int NKB>                       // 16-key blocks: n_ctx <= 16 * NKB
+// NKB 16-key blocks: n_ctx <= 16 * NKB; MASK_ALL = false: n_ctx > 16 (NKB - 1), padded keys only in the last block
+template <int NKB, bool MASK_ALL>
 __global__ __launch_bounds__(64 * kXaWaves) void cross_attn_kernel(const zigma_xattn_params_t p, const int kXaTiles) {
     constexpr int KP = 16 * NKB;                         // keys covered by S
     constexpr int KS = (KP + 31) / 32, KP2 = 32 * KS;    // k-steps / padded keys of the P V product
@@ -97,33 +100,34 @@ __global__ __launch_bounds__(64 * kXaWaves) void cross_attn_kernel(const zigma_x
         // ---- S^T = K Q^T : lane -> token column i16, key rows 16 nb + 4 g + r -----------------------------------------
         f32x4 s[NKB];
 #pragma unroll
-        for (int nb = 0; nb < NKB; ++nb) {
-            s[nb] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int ks = 0; ks < 2; ++ks) {                 // (k-step outermost: consecutive MFMAs on different accumulators; the first on a literal zero)
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
+            for (int nb = 0; nb < NKB; ++nb) {
                 const bf16x8 kf = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4 *>(s_k + (nb * 16 + i16) * kXaKPitch + ks * 64 + g * 16));
-                s[nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qa[ks], s[nb], 0, 0, 0);
+                s[nb] = ks == 0 ? __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qa[ks], f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0)
+                                : __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qa[ks], s[nb], 0, 0, 0);
             }
         }
         // ---- softmax over the keys of this lane's token: 4 NKB values in the lane, the rest in lanes i16 + 16 g' ----------
+        // (raw scores: the positive scale commutes with the maximum and enters the exponent as one fma per key)
         float m = -INFINITY;
 #pragma unroll
         for (int nb = 0; nb < NKB; ++nb) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const float v = (nb * 16 + 4 * g + r < NC) ? s[nb][r] * sc : -INFINITY;
-                s[nb][r] = v;
-                m = fmaxf(m, v);
+                if (MASK_ALL || nb == NKB - 1) s[nb][r] = (nb * 16 + 4 * g + r < NC) ? s[nb][r] : -INFINITY;     // padded keys
+                m = fmaxf(m, s[nb][r]);
             }
         }
         m = fmaxf(m, __shfl_xor(m, 16, 64));
         m = fmaxf(m, __shfl_xor(m, 32, 64));
+        const float msc = -m * sc;
         float sum = 0.f;
 #pragma unroll
         for (int nb = 0; nb < NKB; ++nb) {
             float e[4];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) { e[r] = fast_exp2(s[nb][r] - m); sum += e[r]; }   // exp2(-inf) = 0 for padded keys
+            for (int r = 0; r < 4; ++r) { e[r] = fast_exp2(__builtin_fmaf(s[nb][r], sc, msc)); sum += e[r]; }   // exp2(-inf) = 0 for padded keys
             *reinterpret_cast<uint2 *>(pt + i16 * VPitch + (nb * 16 + 4 * g) * 2) = make_uint2(pack_bf16(e[0], e[1]), pack_bf16(e[2], e[3]));
         }
         if (KP2 > KP) *reinterpret_cast<uint2 *>(pt + i16 * VPitch + (KP + 4 * g) * 2) = make_uint2(0u, 0u);
@@ -135,14 +139,13 @@ __global__ __launch_bounds__(64 * kXaWaves) void cross_attn_kernel(const zigma_x
         // ---- O^T = V^T P^T : lane -> token column i16, dims 16 db + 4 g + r ---------------------------------------------------
         f32x4 o[4];
 #pragma unroll
-        for (int db = 0; db < 4; ++db) o[db] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
             const bf16x8 pf = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4 *>(pt + i16 * VPitch + ks * 64 + g * 16));
 #pragma unroll
             for (int db = 0; db < 4; ++db) {
                 const bf16x8 vf = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4 *>(s_vt + (db * 16 + i16) * VPitch + ks * 64 + g * 16));
-                o[db] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf, o[db], 0, 0, 0);
+                o[db] = ks == 0 ? __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0)
+                                : __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf, o[db], 0, 0, 0);
             }
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -189,8 +192,13 @@ extern "C" int zigma_cross_attn_fwd(const zigma_xattn_params_t *pp, void *stream
     const int tok_per_wg = kXaTok * kXaWaves * tiles;
     dim3 grid((p.seqlen + tok_per_wg - 1) / tok_per_wg, p.heads, p.batch), block(64 * kXaWaves);
     hipStream_t stream = static_cast<hipStream_t>(stream_);
-    if (p.n_ctx <= 80) hipLaunchKernelGGL(cross_attn_kernel<5>, grid, block, 0, stream, p, tiles);
-    else hipLaunchKernelGGL(cross_attn_kernel<8>, grid, block, 0, stream, p, tiles);
+    if (p.n_ctx <= 80) {
+        if (p.n_ctx > 64) hipLaunchKernelGGL((cross_attn_kernel<5, false>), grid, block, 0, stream, p, tiles);
+        else hipLaunchKernelGGL((cross_attn_kernel<5, true>), grid, block, 0, stream, p, tiles);
+    } else {
+        if (p.n_ctx > 112) hipLaunchKernelGGL((cross_attn_kernel<8, false>), grid, block, 0, stream, p, tiles);
+        else hipLaunchKernelGGL((cross_attn_kernel<8, true>), grid, block, 0, stream, p, tiles);
+    }
     set_last_kernel("cross_attn_mfma");
     return check_launch();
 }
