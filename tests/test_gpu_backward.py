@@ -602,3 +602,43 @@ def test_video_temporal_layers_train_without_transposing_copies():
     assert res[True][2].keys() == res[False][2].keys()
     worst = max((rel_err(N(res[True][2][n]), N(res[False][2][n])), n) for n in res[True][2] if float(res[False][2][n].abs().max()) > 0)
     assert worst[0] < 2e-2, worst
+
+
+@pytest.mark.parametrize("M,K,N,bias", [(65536, 640, 2560, False), (16384, 1280, 640, False), (8192, 512, 640, True), (4096, 640, 512, False)])
+def test_linear_train_fn_on_the_own_kernels(M, K, N, bias, monkeypatch):
+    """wgrad.LinearTrainFn (round 4): forward product and dX on zigma_linear_fwd (weight-stationary / tiled kernels) — asserted from the call
+    trace — against float64 on the same bf16 operands and against the library path (F.linear + autograd) within bf16 bounds; dW through
+    the slab-wise product as before (reference: autograd's linear backward behind mamba_simple.py:290-294, model_zigma.py:104-135)."""
+    import zigma_amd.wgrad as wg
+    from zigma_amd import _lib
+    g = torch.Generator(device="cpu").manual_seed(M + K)
+    x = torch.randn(M, K, generator=g).to("cuda", torch.bfloat16).requires_grad_(True)
+    w = (torch.randn(N, K, generator=g) * K ** -0.5).to("cuda", torch.bfloat16).requires_grad_(True)
+    b = (torch.randn(N, generator=g) * 0.1).to("cuda", torch.bfloat16).requires_grad_(True) if bias else None
+    dy = torch.randn(M, N, generator=g).to("cuda", torch.bfloat16)
+    monkeypatch.setattr(wg, "OWN_TRAIN_GEMMS", True)
+    trace = []
+    monkeypatch.setattr(_lib, "TRACE", trace)
+    y = wg.linear_train(x, w, b)
+    y.backward(dy)
+    monkeypatch.setattr(_lib, "TRACE", None)
+    n_own = sum(1 for fn, _, _ in trace if fn == "zigma_linear_fwd")
+    assert n_own == 2, [t[:2] for t in trace]                     # forward and dX
+    got = (y.detach(), x.grad.clone(), w.grad.clone(), None if b is None else b.grad.clone())
+    x.grad = w.grad = None
+    if b is not None:
+        b.grad = None
+    monkeypatch.setattr(wg, "OWN_TRAIN_GEMMS", False)
+    y2 = wg.linear_train(x, w, b)
+    y2.backward(dy)
+    rows = torch.randint(0, M, (512,), generator=g).to("cuda")
+    xd, wd, dyd = x.detach().double(), w.detach().double(), dy.double()
+    ref_y = xd[rows] @ wd.T + (0 if b is None else b.detach().double())
+    ref_dx = dyd[rows] @ wd
+    assert rel_err(got[0][rows].double().cpu().numpy(), ref_y.cpu().numpy()) < 2.5e-3
+    assert rel_err(got[1][rows].double().cpu().numpy(), ref_dx.cpu().numpy()) < 2.5e-3
+    assert rel_err(got[0].float().cpu().numpy(), y2.detach().float().cpu().numpy()) < 2e-3
+    assert rel_err(got[1].float().cpu().numpy(), x.grad.float().cpu().numpy()) < 2e-3
+    assert torch.equal(got[2], w.grad)                            # (the weight gradient does not depend on the switch)
+    if b is not None:
+        assert torch.equal(got[3], b.grad)
