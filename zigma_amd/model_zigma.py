@@ -32,7 +32,7 @@ from torch import Tensor
 from .attention import attention_math, cross_attn, cross_attn_eligible, cross_attn_train
 from . import embed as _embed
 from .layernorm import RMSNorm, block_norm, glue_bwd_eligible, layer_norm_fn, rms_norm_fn, scale_reduce_bwd
-from .linear import gated_residual_eligible, linear, linear_eligible
+from .linear import gated_residual_eligible, linear, linear_eligible, linear_ws_eligible
 from .mamba_simple import Mamba
 from .wgrad import linear_train
 from .scan_paths import hilbert_path, reverse_permut_np, zigzag_path
@@ -126,6 +126,8 @@ class CrossAttention(nn.Module):
 
     @staticmethod
     def _proj(x, lin):
+        if TO_Q_WS and lin.bias is None and linear_ws_eligible(x, lin.weight):
+            return linear(x, lin.weight, weight_stationary=True)
         if linear_eligible(x, lin.weight, lin.bias):
             return linear(x, lin.weight, lin.bias)
         return linear_train(x, lin.weight, lin.bias)       # (F.linear; under autograd with the slab-wise weight gradient, zigma_amd/wgrad.py)
@@ -276,7 +278,8 @@ class Pending:
 # GEMM + the add inside the following norm kernel.  Per block (profiles/r02_b_bench_kernel_stats.csv vs r02_d_*): out_proj 127 -> 150 us,
 # pre-attention add + norm 68 -> 47, and with to_out's gated add: to_out 63 -> 78, pre-mixer add + norm 119 -> 102 — time moves from
 # the HBM-bound norm kernels into the projection epilogues, the forward is 0.1-0.3 % faster.
-TEXT_PROJ_OWN = os.environ.get("ZIGMA_TEXT_PROJ_OWN", "1") == "1"   # y_embedder and the batched K / V projection of all blocks (B x 77 text rows) on zigma_linear_fwd, rows padded to 256
+TEXT_PROJ_OWN = os.environ.get("ZIGMA_TEXT_PROJ_OWN", "1") == "1"
+TO_Q_WS = os.environ.get("ZIGMA_TO_Q_WS", "0") == "1"      # to_q on the weight-stationary kernel (A/B knob: a tie stand-alone)   # y_embedder and the batched K / V projection of all blocks (B x 77 text rows) on zigma_linear_fwd, rows padded to 256
 
 
 def _padded_own_linear(x, weight, bias):
