@@ -91,7 +91,8 @@ __device__ __forceinline__ void mfma_f(f32x16 &acc, const WFrags<KG, FB> &w, con
 }
 
 // PROBE (tools/linear_ws_probe.py; probe builds only): 0 = the kernel, 1 = no epilogue, 2 = default-policy stores instead of nt,
-// 3 = MFMAs only (no stream after the prologue, no barriers, no fragment reads, no epilogue)
+// 3 = MFMAs only (no stream after the prologue, no barriers, no fragment reads, no epilogue), 4 = the direct-to-LDS loads four per k-group from
+// k-group 6 on (the first form) instead of two per k-group from 4 on
 template <int KG, int FB, int PROBE>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
 void linear_ws_kernel(const zigma_linear_params_t p, const int panels, const int ranges, const int tiles_per_xcd) {
@@ -224,7 +225,7 @@ void linear_ws_kernel(const zigma_linear_params_t p, const int panels, const int
             // ONE workgroup barrier per TWO slices: in k-group QS of every odd slice g the slices g + 1 and g + 2 have landed everywhere
             // (each wave has waited for its own parts) and the slots of g - 2 and g - 1 are free for g + 6, g + 7
             const bool sync = (((NS & 1) * PAR + ks) & 1) == 1;             // g = NS t + ks: its parity is known at compile time
-            constexpr int QS = FB == 2 ? 6 : 4, LPG = FB == 2 ? 4 : 2;    // first k-group of the loads behind the barrier; loads per k-group
+            constexpr int QS = (FB == 2 && PROBE == 4) ? 6 : 4, LPG = (FB == 2 && PROBE == 4) ? 4 : 2;    // first k-group of the loads behind the barrier; loads per k-group (PROBE 4: the first form, 4 per group from 6 on)
 #pragma unroll
             for (int q = 0; q < 8; ++q) {
                 // One k-group = 2 FB MFMAs with everything else in the gaps behind them (with a single wave per SIMD whatever sits in
@@ -268,8 +269,8 @@ void linear_ws_kernel(const zigma_linear_params_t p, const int panels, const int
                     }
                     if (mi == 1 && wr_now) wr_chunk_wr(c, dch, sw);             // ---- gap 1
                     if (dma) {                           // the last LPG gaps: FB = 2: 2 loads in gap 1, 1 in gap 2, 1 in gap 3; FB = 1: 1 in gap 0, 1 in gap 1
-                        const int first_l = FB == 2 ? (mi == 1 ? 0 : mi == 2 ? 2 : mi == 3 ? 3 : -1) : mi;
-                        const int n_l = FB == 2 ? (mi == 1 ? 2 : mi >= 2 ? 1 : 0) : 1;
+                        const int first_l = FB == 2 ? (LPG == 4 ? (mi == 1 ? 0 : mi == 2 ? 2 : mi == 3 ? 3 : -1) : mi - 2) : mi;
+                        const int n_l = FB == 2 ? (LPG == 4 ? (mi == 1 ? 2 : mi >= 2 ? 1 : 0) : (mi >= 2 ? 1 : 0)) : 1;
 #pragma unroll
                         for (int li = 0; li < n_l; ++li) {
                             const int l = dl + first_l + li, dd = 6 + (l >> 2);  // load l & 3 of slice g + dd
@@ -347,7 +348,7 @@ int launch_linear_ws(const zigma_linear_params_t &p, hipStream_t stream) {
     const dim3 grid(256), block(256);
 #define ZIGMA_LWS(KG_, FB_, P_) hipLaunchKernelGGL((lws::linear_ws_kernel<KG_, FB_, P_>), grid, block, 0, stream, p, panels, ranges, tiles_per_xcd)
 #ifdef ZIGMA_LINEAR4W_PROBES
-#define ZIGMA_LWS_K(KG_, FB_) { if (probe == 1) ZIGMA_LWS(KG_, FB_, 1); else if (probe == 2) ZIGMA_LWS(KG_, FB_, 2); else if (probe == 3) ZIGMA_LWS(KG_, FB_, 3); else ZIGMA_LWS(KG_, FB_, 0); }
+#define ZIGMA_LWS_K(KG_, FB_) { if (probe == 1) ZIGMA_LWS(KG_, FB_, 1); else if (probe == 2) ZIGMA_LWS(KG_, FB_, 2); else if (probe == 3) ZIGMA_LWS(KG_, FB_, 3); else if (probe == 4) ZIGMA_LWS(KG_, FB_, 4); else ZIGMA_LWS(KG_, FB_, 0); }
 #else
 #define ZIGMA_LWS_K(KG_, FB_) { if (probe) return ZIGMA_ERR_UNSUPPORTED; ZIGMA_LWS(KG_, FB_, 0); }
 #endif
