@@ -61,7 +61,7 @@ for name, K, N in (("in_proj", 640, 2560), ("to_q", 640, 512), ("k512_n1024", 51
     rec["us"] = {k: sorted(v)[len(v) // 2] for k, v in t.items()}
     rec["us_min"] = {k: min(v) for k, v in t.items()}
     rec["probes_us"] = {pn: sorted(timed(lambda: linear(x, w, _probe_flags=0x4000 | fl)) for _ in range(3))[1]
-                        for pn, fl in (("no_epilogue", 0x10000), ("default_policy_stores", 0x20000), ("mfma_only", 0x30000), ("dma_4_per_group_from_6", 0x40000))}
+                        for pn, fl in (("no_epilogue", 0x10000), ("default_policy_stores", 0x20000), ("mfma_only", 0x30000), ("frag_reads_in_front", 0x40000))}
     fl = 2.0 * M * K * N
     rec["PFLOPs"] = {k: fl / (v * 1e-6) / 1e15 for k, v in rec["us"].items()}
     print(json.dumps(rec), flush=True)

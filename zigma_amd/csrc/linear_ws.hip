@@ -91,8 +91,8 @@ __device__ __forceinline__ void mfma_f(f32x16 &acc, const WFrags<KG, FB> &w, con
 }
 
 // PROBE (tools/linear_ws_probe.py; probe builds only): 0 = the kernel, 1 = no epilogue, 2 = default-policy stores instead of nt,
-// 3 = MFMAs only (no stream after the prologue, no barriers, no fragment reads, no epilogue), 4 = the direct-to-LDS loads four per k-group from
-// k-group 6 on (the first form) instead of two per k-group from 4 on
+// 3 = MFMAs only (no stream after the prologue, no barriers, no fragment reads, no epilogue), 4 = the fragment reads in front of the first MFMA
+// of the k-group instead of behind it
 template <int KG, int FB, int PROBE>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
 void linear_ws_kernel(const zigma_linear_params_t p, const int panels, const int ranges, const int tiles_per_xcd) {
@@ -225,13 +225,14 @@ void linear_ws_kernel(const zigma_linear_params_t p, const int panels, const int
             // ONE workgroup barrier per TWO slices: in k-group QS of every odd slice g the slices g + 1 and g + 2 have landed everywhere
             // (each wave has waited for its own parts) and the slots of g - 2 and g - 1 are free for g + 6, g + 7
             const bool sync = (((NS & 1) * PAR + ks) & 1) == 1;             // g = NS t + ks: its parity is known at compile time
-            constexpr int QS = (FB == 2 && PROBE == 4) ? 6 : 4, LPG = (FB == 2 && PROBE == 4) ? 4 : 2;    // first k-group of the loads behind the barrier; loads per k-group (PROBE 4: the first form, 4 per group from 6 on)
+            constexpr int QS = 4, LPG = 2;           // first k-group of the loads behind the barrier; loads per k-group (four per group from 6 on: 180.8 vs 177.6 us)
 #pragma unroll
             for (int q = 0; q < 8; ++q) {
                 // One k-group = 2 FB MFMAs with everything else in the gaps behind them (with a single wave per SIMD whatever sits in
                 // FRONT of the first MFMA runs with the matrix pipe idle):
-                //   front  the fragments of this group have landed: lgkmcnt(LDS instructions issued behind their reads); the reads of the NEXT group
-                //   gap 0  store of the epilogue piece read one group ago, read-back of the next piece | write chunk, first half
+                //   front  the fragments of this group have landed: lgkmcnt(LDS instructions issued behind their reads)
+                //   gap 0  the fragment reads of the NEXT group; store of the epilogue piece read one group ago, read-back of the next piece | write
+                //          chunk, first half
                 //   gap 1  write chunk, second half; direct-to-LDS loads (LPG per k-group from QS on, in the last gaps)
                 const int qg = ks * 8 + q, r = qg - R0, c = qg - W0;
                 const bool wr_prev = EPI && c - 1 >= 0 && c - 1 < NWC, rd_prev = EPI && r - 1 >= 0 && r - 1 < NRC;
@@ -242,16 +243,13 @@ void linear_ws_kernel(const zigma_linear_params_t p, const int panels, const int
                 }
                 if (PROBE == 3) wait_lgkm<0>(); else wait_lgkm_n((wr_prev ? 1 : 0) + (rd_prev ? 1 : 0));
                 const bool first = qg == 0;
-                if (PROBE == 3) {
-                } else if (q < 7) {
-                    const unsigned ad = (ao ^ ((q + 1) << 5)) + sb;
+                auto frag_reads = [&]() {                // the fragments of the NEXT k-group (this slice or, from k-group 7, the next one)
+                    if (PROBE == 3) return;
+                    const unsigned ad = q < 7 ? (ao ^ ((q + 1) << 5)) + sb : ao + sb1;
                     lds_rd<0>(bf[(q + 1) & 1][0], ad);
                     lds_rd<8192>(bf[(q + 1) & 1][1], ad);
-                } else {
-                    const unsigned ad = ao + sb1;
-                    lds_rd<0>(bf[0][0], ad);
-                    lds_rd<8192>(bf[0][1], ad);
-                }
+                };
+                if (PROBE == 4) frag_reads();            // (PROBE 4: in front of the first MFMA, where the matrix pipe waits for them to issue: 180 vs 175 us)
                 // the direct-to-LDS loads behind a barrier: slice g + 6 first, then slice g + 7, LPG per k-group
                 const int dl = (q - QS) * LPG;                                   // first load of this k-group: 0 .. 7
                 const bool dma = PROBE != 3 && sync && q >= QS && dl < 8;
@@ -260,6 +258,7 @@ void linear_ws_kernel(const zigma_linear_params_t p, const int panels, const int
                     const int tb = mi / FB, fb = mi % FB;
                     mfma_f<KG, FB>(acc[PAR][mi], w, FB * qg + fb, first, bf[q & 1][tb]);
                     if (mi == 0) {                       // ---- gap 0
+                        if (PROBE != 4) frag_reads();
                         if (rd_prev) {
                             wait_lgkm<2>();              // the chunk read one group ago has landed: behind it in the LDS queue sit only the two fragment reads above
                             st_chunk(o, ot, r - 1);
@@ -268,9 +267,9 @@ void linear_ws_kernel(const zigma_linear_params_t p, const int panels, const int
                         if (wr_now) wr_chunk_rd(acc[PAR ^ 1], c, dch);
                     }
                     if (mi == 1 && wr_now) wr_chunk_wr(c, dch, sw);             // ---- gap 1
-                    if (dma) {                           // the last LPG gaps: FB = 2: 2 loads in gap 1, 1 in gap 2, 1 in gap 3; FB = 1: 1 in gap 0, 1 in gap 1
-                        const int first_l = FB == 2 ? (LPG == 4 ? (mi == 1 ? 0 : mi == 2 ? 2 : mi == 3 ? 3 : -1) : mi - 2) : mi;
-                        const int n_l = FB == 2 ? (LPG == 4 ? (mi == 1 ? 2 : mi >= 2 ? 1 : 0) : (mi >= 2 ? 1 : 0)) : 1;
+                    if (dma) {                           // the last LPG gaps: FB = 2: gaps 2 and 3; FB = 1: gaps 0 and 1
+                        const int first_l = FB == 2 ? mi - 2 : mi;
+                        const int n_l = FB == 2 ? (mi >= 2 ? 1 : 0) : 1;
 #pragma unroll
                         for (int li = 0; li < n_l; ++li) {
                             const int l = dl + first_l + li, dd = 6 + (l >> 2);  // load l & 3 of slice g + dd
