@@ -438,3 +438,29 @@ def test_linear_train_fn_matches_autograd_and_slab_rule():
     for m, n, k in ((65536, 2560, 640), (65536, 72, 1280), (65536, 1280, 40), (4096, 512, 640), (1000, 64, 64), (256, 640, 640)):
         s = _slabs(m, n, k)
         assert s >= 1 and (s & (s - 1)) == 0 and (s == 1 or (m % s == 0 and m // s >= 256 and (m // s) % 8 == 0)), (m, n, k, s)
+
+
+@pytest.mark.parametrize("m,n", [(65536, 2560), (65536, 512), (32768, 2560), (4096, 8192), (5632, 1024), (512 * 43, 256), (16384, 1280)])
+def test_linear_ws_work_partition_covers_every_tile_once(m, n):
+    """The workgroup -> (panel, token range) assignment of csrc/linear_ws.hip restated: XCD x = blockIdx % 8 owns the x-th eighth of the 64-token
+    tiles, slot = blockIdx / 8 -> panel = slot % panels, range = slot / panels, the range's tiles split as evenly as integers allow.  Every
+    (panel, tile) pair must be computed by exactly one workgroup, ranges must be non-empty, and the per-workgroup tile counts of one launch
+    may differ by at most one (the kernel's load balance)."""
+    panels, tiles_per_xcd = n // 256, m // 512
+    ranges = 32 // panels
+    assert tiles_per_xcd >= ranges
+    seen, counts = {}, []
+    for block in range(256):
+        xcd, slot = block & 7, block >> 3
+        if slot >= panels * ranges:
+            continue
+        panel, rng = slot % panels, slot // panels
+        t_lo = xcd * tiles_per_xcd + (rng * tiles_per_xcd) // ranges
+        t_hi = xcd * tiles_per_xcd + ((rng + 1) * tiles_per_xcd) // ranges
+        assert t_hi > t_lo
+        counts.append(t_hi - t_lo)
+        for t in range(t_lo, t_hi):
+            assert (panel, t) not in seen
+            seen[(panel, t)] = block
+    assert len(seen) == panels * (m // 64)
+    assert max(counts) - min(counts) <= 1
