@@ -19,9 +19,12 @@ def timed(fn, n=10):
     for _ in range(n): fn()
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / n * 1e3
+ya, yb = fa(), fb()
+torch.cuda.synchronize()
+equal = bool(torch.equal(ya, yb))
 for _ in range(3): fa(); fb()
 ta, tb = [], []
 for _ in range(12):
     ta.append(timed(fa)); tb.append(timed(fb))
 med = lambda v: sorted(v)[len(v) // 2]
-print(json.dumps(dict(shape=f"M={M} K={K} N={N}", flag=hex(flag), default_us=med(ta), variant_us=med(tb), default_min=min(ta), variant_min=min(tb))))
+print(json.dumps(dict(shape=f"M={M} K={K} N={N}", flag=hex(flag), equal=equal, finite=bool(torch.isfinite(yb.float()).all()), frac_diff=float((ya != yb).float().mean()), default_us=med(ta), variant_us=med(tb), default_min=min(ta), variant_min=min(tb))))
