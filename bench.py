@@ -425,7 +425,7 @@ def main():
         if timer.pairs:
             ms = timer.mean_ms()
             ach = algo_bytes / (ms * 1e-3)
-            traffic, traffic_src = (None, None) if args.no_cpu_baseline else pmc_traffic_live()      # (both are the slow, untimed legs)
+            traffic, traffic_src = (None, None) if (args.no_cpu_baseline or world > 1) else pmc_traffic_live()      # (both are the slow, untimed legs; N = 1 only)
             if traffic is None:
                 traffic, traffic_src = pmc_traffic()
             # VALU floor of the recurrence at the guide's issue rates (MI355X_MICROARCH.md: v_fma_f32 2 cycles per wave64
