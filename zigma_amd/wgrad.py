@@ -7,10 +7,10 @@ into S slabs as a BATCHED GEMM (the slab index is the library's batch dimension)
 results (bf16, like a GEMM output) are added in fp32: in_proj 332 us, out_proj 303 -> 149, to_q 259 -> 76, to_out 271 -> 66,
 x_proj 227 -> 72, dt_proj 205 -> 64 us — 17 ms of a 122 ms training step.  `LinearTrainFn` is F.linear with that backward; since round 4 its forward product and dX run on the hand-written projection kernels
 (zigma_linear_fwd) where one serves the shape — `OWN_TRAIN_GEMMS`."""
+import os
+
 import torch
 import torch.nn.functional as F
-
-import os
 
 SPLIT_WGRAD = True        # False: one GEMM (A/B in tools/train_probe.py)
 # forward projection and dX = dY W of the training path on the hand-written MFMA kernels (zigma_linear_fwd: weight-stationary / tiled) where they
