@@ -25,6 +25,9 @@ NO_COPY_TEMPORAL = True      # video "t" layers on strided views (False: the tra
 IN_PROJ_SPLIT = os.environ.get("ZIGMA_IN_PROJ_SPLIT", "1") == "1"      # in_proj as two half-width launches of the own kernel
 IN_PROJ_SPLIT_MIN_TOKENS = 32768
 IN_PROJ_WS = os.environ.get("ZIGMA_IN_PROJ_WS", "1") == "1"            # in_proj on the weight-stationary kernel (csrc/linear_ws.hip) where it serves the shape
+# ... from 8192 tokens on: 33.5 us against 41.5 (library) / 37.1 (tiled kernel) there, 52 / 72 / 59 at 16 384, 93 / 106 / 106 at 32 768; a tie at 4096
+# (tools/linear_ws_probe.py with M=...)
+IN_PROJ_WS_MIN_TOKENS = 8192
 
 
 def _int32_table(t, device):
@@ -269,7 +272,7 @@ class Mamba(nn.Module):
         if linear_eligible(x, lin.weight, lin.bias):
             return linear(x, lin.weight, lin.bias)
         n = lin.weight.shape[0]
-        if IN_PROJ_WS and lin.bias is None and x.shape[:-1].numel() >= IN_PROJ_SPLIT_MIN_TOKENS and linear_ws_eligible(x, lin.weight):
+        if IN_PROJ_WS and lin.bias is None and x.shape[:-1].numel() >= IN_PROJ_WS_MIN_TOKENS and linear_ws_eligible(x, lin.weight):
             # ONE launch, W_in panels resident in registers, only the tokens stream (half the L2 -> LDS bytes of the tiled kernel)
             return linear(x, lin.weight, weight_stationary=True)
         if (IN_PROJ_SPLIT and lin.bias is None and n % 512 == 0 and n >= 2048 and x.dim() == 3
