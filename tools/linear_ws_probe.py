@@ -30,7 +30,7 @@ def timed(fn, n=10):
     return e0.elapsed_time(e1) / n * 1e3
 
 
-for name, K, N in (("in_proj", 640, 2560),):
+for name, K, N in (("in_proj", 640, 2560), ("to_q", 640, 512), ("k512_n1024", 512, 1024)):
     x = torch.randn(M, K, device=dev, dtype=dt)
     w = (torch.randn(N, K, device=dev) * K ** -0.5).to(dt)
     y4 = linear(x, w)
