@@ -365,6 +365,8 @@ def main():
     ap.add_argument("--batch", type=int, default=None, help="per-GPU batch (default: the workload's)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-scan-events", action="store_true")
+    ap.add_argument("--no-check", action="store_true",
+                    help="skip the untimed self-check forward (kernel traces of the timed path: its unfused composition runs library GEMMs)")
     ap.add_argument("--cpu-baseline-only", default=None, help=argparse.SUPPRESS)      # child-process leg of cpu_baseline()
     args = ap.parse_args()
     if args.cpu_baseline_only:
@@ -407,7 +409,7 @@ def main():
     for _ in range(args.warmup):          # scan-event timing only inside the timed region
         step()
     v_check = step()                      # (every rank: the step holds the gather)
-    check = check_against_unfused(model, x, t, y, v_check) if rank == 0 else None       # outside the timed region
+    check = check_against_unfused(model, x, t, y, v_check) if (rank == 0 and not args.no_check) else None       # outside the timed region
     timer.enabled = not args.no_scan_events
     elapsed = ss.timed_steps(step, args.steps, 0, device, world)
     timer.enabled = False
