@@ -397,7 +397,7 @@ typedef struct zigma_xattn_params {
     int32_t batch, seqlen, n_ctx, heads, head_dim;
     int32_t dtype;
     int32_t flags;   /* reserved, must be 0 */
-    float scale;     /* head_dim^-0.5 in the reference */
+    float scale;     /* head_dim^-0.5 in the reference; must be finite and > 0 (else ZIGMA_ERR_UNSUPPORTED) */
     int64_t q_batch_stride, q_row_stride;
     int64_t k_batch_stride, k_row_stride;
     int64_t v_batch_stride, v_row_stride;

@@ -3,7 +3,7 @@
 
 TEST INFRASTRUCTURE.  Run in the build container only (the GPU box has no /root/reference):
 
-    python oracle/make_golden.py
+    python -m oracle.make_golden        (or: python oracle/make_golden.py — all four make_golden* scripts take both forms)
 
 Everything stored is float32 / int64 numpy, produced by the reference's own functions:
   selective_scan_ref   dis_mamba/mamba_ssm/ops/selective_scan_interface.py:86-152
@@ -25,8 +25,8 @@ import torch
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 OUT = os.path.join(os.path.dirname(HERE), "tests", "golden")
-sys.path.insert(0, HERE)
-import ref_shim  # noqa: E402
+sys.path.insert(0, os.path.dirname(HERE))           # the repo root: `python -m oracle.make_golden` and `python oracle/make_golden.py` both work
+from oracle import ref_shim  # noqa: E402
 
 
 def npy(t):

@@ -12,7 +12,10 @@ import os
 import numpy as np
 import torch
 
-from . import bwd_cases, ref_shim
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))     # repo root: `python -m oracle.make_golden_bwd` or `python oracle/make_golden_bwd.py`
+from oracle import bwd_cases, ref_shim  # noqa: E402
 
 OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
 

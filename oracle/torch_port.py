@@ -13,7 +13,7 @@ F.softplus / F.silu / F.conv1d / F.linear — so that its timing is the referenc
   rms_norm_ref / layer_norm_ref   dis_mamba/mamba_ssm/ops/triton/layernorm.py:19-48
   Mamba zigzag branch     dis_mamba/mamba_ssm/modules/mamba_simple.py:274-298,356-395
   Block / ZigMa forward   model_zigma.py:388-460,911-990 (has_text / class / unconditional; zigzagN / hilbertN / v1)
-Pinned: tests/test_oracle_cpu.py::test_torch_port_* compare it with the golden outputs of the unmodified reference
+Pinned: tests/test_oracle_golden.py::test_torch_port_* (lines 123-160) compare it with the golden outputs of the unmodified reference
 (tests/golden/*.npz) — the same fixtures that pin the numpy oracle."""
 import math
 

@@ -494,20 +494,85 @@ def test_scan_tok2_dt_proj_in_kernel_vs_oracle(Bsz, L, Di, R, use_perm, io):
 
 
 def test_scan_dt_in_kernel_limits():
-    from zigma_amd.selective_scan_interface import scan_raw
+    """What the in-kernel dt_proj (zigma_scan_params_t.dt_x) refuses — the limits tok2_dtp_ok() states, each hit on its own: with dt_x
+    set no other kernel serves the call, so the C side answers ZIGMA_ERR_UNSUPPORTED and the caller has to keep the dt_proj kernel."""
+    from zigma_amd.selective_scan_interface import dt_in_scan_eligible, scan_raw
     Bsz, L, Di, R, Nst = 1, 32, 64, 40, 16
     ut = torch.randn(Bsz, L, Di, device=DEV).bfloat16()
     xt = torch.randn(Bsz, L, R + 2 * Nst, device=DEV).bfloat16()
     wt = torch.randn(Di, R, device=DEV).bfloat16()
     A = -torch.rand(Di, Nst, device=DEV)
     Bv, Cv = xt[:, :, R:R + Nst].transpose(1, 2).unsqueeze(1), xt[:, :, R + Nst:].transpose(1, 2).unsqueeze(1)
+    ok = lambda **kw: scan_raw(ut.transpose(1, 2), None, A, Bv, Cv, None, ut.transpose(1, 2), None, True, want_out=False,
+                               **{"dt_x": xt, "dt_w": wt, **kw})
+    ok()                                    # the base case is served (so every refusal below is the one limit it names)
+    assert dt_in_scan_eligible(ut, xt, wt, dstate=Nst, z=ut)
     with pytest.raises(RuntimeError):       # delta=None without the pair
         scan_raw(ut.transpose(1, 2), None, A, Bv, Cv, None, ut.transpose(1, 2), None, True)
-    with pytest.raises(RuntimeError):       # fp16 operands: the in-kernel product is bf16 only
-        scan_raw(ut.half().transpose(1, 2), None, A, Bv.half(), Cv.half(), None, ut.half().transpose(1, 2), None, True,
-                 dt_x=xt.half(), dt_w=wt.half())
     with pytest.raises(RuntimeError):       # dt_rank < 32
-        scan_raw(ut.transpose(1, 2), None, A, Bv, Cv, None, ut.transpose(1, 2), None, True, dt_x=xt, dt_w=wt[:, :16].contiguous())
+        ok(dt_w=wt[:, :16].contiguous())
+    with pytest.raises(RuntimeError):       # dt_rank % 8 != 0 (36 columns of the 40-wide rows)
+        ok(dt_w=wt[:, :36])
+    assert not dt_in_scan_eligible(ut, xt, wt[:, :36], dstate=Nst)
+    with pytest.raises(RuntimeError):       # reset_period (the video temporal layers keep the dt_proj kernel)
+        ok(reset_period=16)
+    assert not dt_in_scan_eligible(ut, xt, wt, reset_period=16, dstate=Nst)
+    with pytest.raises(RuntimeError):       # a carry buffer (sequence split) together with dt_x
+        ok(x=torch.empty(Bsz, Di, 2, 2 * Nst, device=DEV), chunk_len=16)
+    with pytest.raises(RuntimeError):       # the training form (ungated out) together with dt_x
+        ok(out=torch.empty_like(ut).transpose(1, 2), want_out=True)
+    # dt_x rows narrower than the 64 columns the two A fragments read
+    xn = torch.randn(Bsz, L, 32 + 2 * Nst - 8, device=DEV).bfloat16()        # 56 columns: dt_rank 32 fits, the second fragment does not
+    with pytest.raises(RuntimeError):
+        scan_raw(ut.transpose(1, 2), None, A, xn[:, :, 24:40].transpose(1, 2).unsqueeze(1), xn[:, :, 40:56].transpose(1, 2).unsqueeze(1), None,
+                 ut.transpose(1, 2), None, True, want_out=False, dt_x=xn, dt_w=wt[:, :32].contiguous())
+    assert not dt_in_scan_eligible(ut, xn, wt[:, :32].contiguous(), dstate=Nst)
+    # dstate != 16: the hot kernel is a 4 waves x 4 states kernel
+    A8 = -torch.rand(Di, 8, device=DEV)
+    x8 = torch.randn(Bsz, L, 64, device=DEV).bfloat16()
+    with pytest.raises(RuntimeError):
+        scan_raw(ut.transpose(1, 2), None, A8, x8[:, :, 40:48].transpose(1, 2).unsqueeze(1), x8[:, :, 48:56].transpose(1, 2).unsqueeze(1), None,
+                 ut.transpose(1, 2), None, True, want_out=False, dt_x=x8, dt_w=wt)
+    assert not dt_in_scan_eligible(ut, x8, wt, dstate=8)
+    # fp16 operands ARE served (the f16 form of the MFMA): B / C as strided views of the fp16 x_dbl rows, like the model passes them
+    xh, uh = xt.half(), ut.half()
+    scan_raw(uh.transpose(1, 2), None, A, xh[:, :, R:R + Nst].transpose(1, 2).unsqueeze(1), xh[:, :, R + Nst:].transpose(1, 2).unsqueeze(1), None,
+             uh.transpose(1, 2), None, True, want_out=False, dt_x=xh, dt_w=wt.half())
+
+
+@pytest.mark.parametrize("d_state", [8, 16, 32])
+def test_mamba_inner_tok_other_state_sizes(d_state):
+    """with dt_proj inside the scan on by default, a bf16 Mamba with d_state 8 or 32 (dt_rank 32..64) must not reach the
+    hot kernel's dt_x form — the gate mirrors tok2_layout_ok (dstate == 16) — and still has to run (dt_proj kernel + first-generation /
+    generic scan) and agree with the oracle."""
+    from oracle import zigma_oracle as zo
+    from zigma_amd.selective_scan_interface import mamba_inner_tok
+    from zigma_amd import _lib
+    torch.manual_seed(3)
+    Bsz, L, Di, R = 2, 64, 128, 48
+    xz = torch.randn(Bsz, L, 2 * Di, device=DEV).bfloat16()
+    cw, cb = (0.4 * torch.randn(Di, 1, 4, device=DEV)).bfloat16(), (0.1 * torch.randn(Di, device=DEV)).bfloat16()
+    xw = (torch.randn(R + 2 * d_state, Di, device=DEV) / Di ** 0.5).bfloat16()
+    dw = (torch.randn(Di, R, device=DEV) / R ** 0.5).bfloat16()
+    A = -torch.exp(torch.log(torch.arange(1, d_state + 1, device=DEV).float()).repeat(Di, 1)).contiguous()
+    D, db = torch.randn(Di, device=DEV), torch.rand(Di, device=DEV) - 2.0
+    perm = torch.randperm(L, device=DEV).to(torch.int32)
+    y = mamba_inner_tok(xz, cw, cb, xw, dw, A, D, db, perm=perm)
+    name = _lib.last_kernel()
+    assert ("dtproj" in name) == (d_state == 16), name
+    f = lambda t: t.float().cpu().numpy().astype(np.float64)
+    bf = lambda a: zo.bf16_round(np.asarray(a, np.float32)).astype(np.float64)
+    pn = perm.cpu().numpy()
+    xs = f(xz)[:, pn, :Di].transpose(0, 2, 1)                                  # (B, Di, L) in scan order
+    u = bf(zo.causal_conv1d(xs, f(cw).reshape(Di, 4), f(cb), activation="silu", dt=np.float64))
+    x_dbl = bf(np.einsum("bdl,nd->bln", u, f(xw)))
+    delta = np.einsum("blr,dr->bdl", x_dbl[:, :, :R], f(dw))
+    Bm, Cm = x_dbl[:, :, R:R + d_state].transpose(0, 2, 1), x_dbl[:, :, R + d_state:].transpose(0, 2, 1)
+    z = f(xz)[:, pn, Di:].transpose(0, 2, 1)
+    ref = zo.selective_scan(u, delta, f(A), Bm, Cm, f(D), z, f(db), True, dt=np.float64)   # (B, Di, L), scan order
+    got = f(y)[:, pn].transpose(0, 2, 1)
+    e = rel_err(got, ref)
+    assert np.isfinite(got).all() and e < 1e-2, e          # (bf16 delta on the dt_proj-kernel route: 2^-9 on every step size)
 
 
 # ---------------------------------------------------------------------------------------------------

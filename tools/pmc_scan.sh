@@ -4,6 +4,7 @@ R=${GRAFT_REPO_ROOT:-$PWD}
 cd /tmp && export TMPDIR=/tmp
 for pass in "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY" \
             "SQ_ACTIVE_INST_ANY SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_INSTS_VMEM GRBM_GUI_ACTIVE" \
+            "SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_BUSY_CU_CYCLES" \
             "FETCH_SIZE" "WRITE_SIZE"; do
   tag=$(echo $pass | cut -d' ' -f1)
   timeout 120 rocprofv3 --pmc $pass --output-format csv -d $R/gpurun_out/pmc_$tag -o pmc -- python $R/tools/scan_one.py > $R/gpurun_out/pmc_$tag.log 2>&1

@@ -180,6 +180,9 @@ extern "C" int zigma_cross_attn_fwd(const zigma_xattn_params_t *pp, void *stream
     const zigma_xattn_params_t &p = *pp;
     if (p.batch < 0 || p.seqlen < 0 || p.heads < 1 || p.n_ctx < 1) return ZIGMA_ERR_SHAPE;
     if (p.flags != 0) return ZIGMA_ERR_UNSUPPORTED;
+    // the softmax takes its maximum over the RAW scores and folds the scale into the exponent (fma(s, sc, -m * sc)): that is the
+    // maximum of the scaled scores only for a positive scale (the reference's is head_dim^-0.5)
+    if (!(p.scale > 0.f) || !(p.scale < 3.0e38f)) return ZIGMA_ERR_UNSUPPORTED;
     if (p.batch == 0 || p.seqlen == 0) return ZIGMA_OK;
     if (!p.q || !p.k || !p.v || !p.out) return ZIGMA_ERR_NULL;
     if (p.dtype != ZIGMA_BF16) return ZIGMA_ERR_DTYPE;

@@ -253,14 +253,25 @@ def conv_x_proj(x_half, conv_w, conv_b, x_proj_weight, perm=None, _flags=0):
 DT_PROJ_IN_SCAN = os.environ.get("ZIGMA_DT_IN_SCAN", "1") == "1"     # dt_proj + softplus in the scan's tile prologue (MFMA) instead of a kernel of its own
 
 
-def dt_in_scan_eligible(u, x_dbl, weight, reset_period=0, out=None):
-    """limits of the in-kernel dt_proj of scan_tok2_kernel (zigma_scan_params_t.dt_x): bf16 / fp16, whole-sequence mode of the hot kernel
-    (seqlen % 16 == 0, d_inner % 64 == 0, no reset_period), 32 <= dt_rank <= 64 and % 8 == 0, x_dbl rows >= 64 wide, 16-byte aligned rows"""
+def dt_in_scan_eligible(u, x_dbl, weight, reset_period=0, out=None, dstate=16, z=None):
+    """limits of the in-kernel dt_proj of scan_tok2_kernel (zigma_scan_params_t.dt_x), mirroring tok2_dtp_ok() / tok2_layout_ok() /
+    tok_eligible() of csrc/: bf16 / fp16, whole-sequence mode of the hot kernel (dstate == 16, seqlen % 16 == 0, d_inner % 64 == 0, no
+    reset_period), 32 <= dt_rank <= 64 and % 8 == 0, x_dbl rows >= 64 wide on 16-byte boundaries, channel-contiguous u / z, and every
+    in-sample offset (seqlen * row stride, in bytes of up to 4-byte elements) below 2^31 / 4.  A caller that gets False keeps the
+    dt_proj kernel (or F.linear) + the ordinary scan call, which serves every shape the reference does."""
     R = weight.shape[1]
-    return (u.is_cuda and u.dtype in (torch.bfloat16, torch.float16) and x_dbl.dtype == u.dtype and weight.dtype == u.dtype and not reset_period
-            and 32 <= R <= 64 and R % 8 == 0 and u.shape[1] % 16 == 0 and u.shape[2] % 64 == 0 and x_dbl.dim() == 3 and x_dbl.shape[2] >= 64
-            and x_dbl.stride(2) == 1 and x_dbl.stride(1) % 8 == 0 and x_dbl.stride(0) % 8 == 0 and weight.stride(1) == 1 and weight.stride(0) % 8 == 0
-            and x_dbl.data_ptr() % 16 == 0 and weight.data_ptr() % 16 == 0 and u.shape[0] <= 65535)
+    if not (u.is_cuda and u.dtype in (torch.bfloat16, torch.float16) and x_dbl.dtype == u.dtype and weight.dtype == u.dtype and not reset_period
+            and dstate == 16 and u.dim() == 3 and x_dbl.dim() == 3
+            and 32 <= R <= 64 and R % 8 == 0 and u.shape[1] % 16 == 0 and u.shape[2] % 64 == 0 and x_dbl.shape[2] >= 64 and x_dbl.shape[2] >= R + 2 * dstate
+            and u.stride(2) == 1 and x_dbl.stride(2) == 1 and x_dbl.stride(1) % 8 == 0 and x_dbl.stride(0) % 8 == 0 and x_dbl.stride(1) >= 64
+            and weight.stride(1) == 1 and weight.stride(0) % 8 == 0
+            and x_dbl.data_ptr() % 16 == 0 and weight.data_ptr() % 16 == 0 and u.shape[0] <= 65535):
+        return False
+    L, lim = u.shape[1], ((1 << 31) - 1) // 4
+    rows = [u.stride(1), x_dbl.stride(1)] + ([z.stride(1)] if z is not None else []) + ([out.stride(1)] if out is not None else [])
+    if z is not None and z.stride(2) != 1:
+        return False
+    return all(0 <= s and s * L <= lim for s in rows)
 
 
 def dt_proj_eligible(x_dbl, dt_rank, weight):
@@ -576,7 +587,8 @@ def _inner_tok_tail(u, x_dbl, z_half, delta_proj_weight, A, D, delta_bias, perm,
     Bsz, L, Di = u.shape
     R = delta_proj_weight.shape[1]
     N = A.shape[1]
-    in_scan = (DT_PROJ_IN_SCAN and delta_softplus and dt_in_scan_eligible(u, x_dbl, delta_proj_weight, reset_period, out)
+    in_scan = (DT_PROJ_IN_SCAN and delta_softplus and not z_preactivated
+               and dt_in_scan_eligible(u, x_dbl, delta_proj_weight, reset_period, out, dstate=N, z=z_half)
                and B_proj_bias is None and C_proj_bias is None and not split_chunk_len(Bsz, Di, L, reset_period))
     if in_scan:                      # dt_proj + bias + softplus inside the scan kernel's tile prologue: delta is never materialised
         delta = None

@@ -18,16 +18,60 @@ SPLIT_WGRAD = True        # False: one GEMM (A/B in tools/train_probe.py)
 OWN_TRAIN_GEMMS = os.environ.get("ZIGMA_TRAIN_OWN_GEMMS", "1") == "1"
 
 
-def _own_linear(x, weight, bias=None):
-    """x @ weight^T (+ bias) on zigma_linear_fwd if a kernel of it serves the call (autograd is off in here), else None"""
+def _bmm_takes_out_dtype():
+    """does this torch's bmm accept out_dtype (fp32 results from 16-bit operands)?  Probed ONCE, on the signature error only — a
+    catch-all around the real call would also swallow an out-of-memory error and silently retry at lower precision."""
+    try:
+        torch.bmm(torch.zeros(1, 1, 1, dtype=torch.bfloat16), torch.zeros(1, 1, 1, dtype=torch.bfloat16), out_dtype=torch.float32)
+        return True
+    except TypeError:
+        return False
+    except RuntimeError:        # (the argument exists; this build has no CPU kernel for it)
+        return True
+
+
+_BMM_OUT_DTYPE = _bmm_takes_out_dtype()
+
+
+def _own_linear(x, weight, bias=None, transposed=False):
+    """x @ weight^T (+ bias) on zigma_linear_fwd if a kernel of it serves the call (autograd is off in here), else None.
+    transposed: the product wanted is x @ weight (dX = dY W) — the transposed copy of the weight is only made once a kernel is known to
+    take the call (eligibility is decided on shapes, dtypes and alignment, which the copy does not change)"""
     from .linear import linear, linear_eligible, linear_ws_eligible
-    if not OWN_TRAIN_GEMMS or not x.is_cuda or x.dtype != torch.bfloat16:
+    if not OWN_TRAIN_GEMMS or not x.is_cuda or x.dtype != torch.bfloat16 or weight.dtype != torch.bfloat16:
         return None
+    if transposed:
+        wt = _ContiguousLike(weight)
+        if not ((bias is None and linear_ws_eligible(x, wt)) or linear_eligible(x, wt, bias, prefer_own=True)):
+            return None
+        weight = weight.t().contiguous()
     if bias is None and linear_ws_eligible(x, weight):
         return linear(x, weight, weight_stationary=True)
     if linear_eligible(x, weight, bias, prefer_own=True):
         return linear(x, weight, bias)
     return None
+
+
+class _ContiguousLike:
+    """Stand-in for `weight.t().contiguous()` in the eligibility predicates of linear.py, which read device, dtype, shape, strides and the
+    16-byte alignment of data_ptr (a fresh allocation is aligned) — so the decision can be taken before the copy is made."""
+
+    def __init__(self, weight):
+        self.is_cuda, self.dtype, self.device, self.requires_grad = weight.is_cuda, weight.dtype, weight.device, False
+        self.shape = torch.Size((weight.shape[1], weight.shape[0]))
+
+    def stride(self, i=None):
+        st = (self.shape[1], 1)
+        return st if i is None else st[i]
+
+    def dim(self):
+        return 2
+
+    def data_ptr(self):
+        return 0
+
+    def is_contiguous(self):
+        return True
 
 
 def _slabs(m, n, k):
@@ -51,9 +95,9 @@ def wgrad(dy2, x2):
     dy3 = dy2.reshape(s, m // s, n)
     x3 = x2.reshape(s, m // s, k)
     # fp32 slab partials (one rounding at the end, like the single GEMM of the reference; a 16-bit partial could also overflow in fp16)
-    try:
+    if _BMM_OUT_DTYPE:
         part = torch.bmm(dy3.transpose(1, 2), x3, out_dtype=torch.float32)
-    except (TypeError, RuntimeError):      # (a torch without out_dtype on bmm)
+    else:                                  # (a torch without out_dtype on bmm)
         part = torch.bmm(dy3.transpose(1, 2), x3).float()
     return part.sum(0).to(dy2.dtype)
 
@@ -75,7 +119,7 @@ class LinearTrainFn(torch.autograd.Function):
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
             dyc = dy2 if dy2.is_contiguous() else dy2.contiguous()
-            dx = _own_linear(dyc, weight.t().contiguous())         # dX = dY W = dY (W^T)^T: the same kernels on the transposed weight (a few MB)
+            dx = _own_linear(dyc, weight, transposed=True)         # dX = dY W = dY (W^T)^T: the same kernels on the transposed weight (a few MB)
             dx = (dy2 @ weight).view(x.shape) if dx is None else dx.view(x.shape)
         if ctx.needs_input_grad[1]:
             dw = wgrad(dy2, x.reshape(-1, x.shape[-1]))
