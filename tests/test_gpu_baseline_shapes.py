@@ -96,7 +96,7 @@ def _trace_counts(trace):
     return counts, gated
 
 
-@pytest.mark.parametrize("variant", ["default", "unfused_out_proj", "linear_all", "linear_off", "default_b32", "in_proj_halves_b32"])
+@pytest.mark.parametrize("variant", ["default", "unfused_out_proj", "linear_all", "linear_off", "default_b32", "in_proj_halves_b32", "gate_in_in_proj_b32"])
 def test_bench_block_path_vs_reference(variant, monkeypatch):
     """The composition bench.py times: README model, bf16, B = 16 -> 16 384 tokens, so that every size
     gate of the hot path opens — the one-pass conv + x_proj kernel, out_proj with the block's gated add in its epilogue
@@ -126,6 +126,9 @@ def test_bench_block_path_vs_reference(variant, monkeypatch):
     elif variant == "in_proj_halves_b32":
         import zigma_amd.mamba_simple as zms
         monkeypatch.setattr(zms, "IN_PROJ_WS", False)
+    elif variant == "gate_in_in_proj_b32":                  # round 5: silu(z) written by in_proj's epilogue, the scan takes the gate as it finds it
+        import zigma_amd.mamba_simple as zms
+        monkeypatch.setattr(zms, "GATE_IN_IN_PROJ", True)
     trace = []
     monkeypatch.setattr(_lib, "TRACE", trace)
     with torch.no_grad():
@@ -147,7 +150,11 @@ def test_bench_block_path_vs_reference(variant, monkeypatch):
     else:                               # sequence-split mode (small batches): the dt_proj kernel of its own
         assert dt_in_scan == 0 and n_dt == depth, counts
     n_ws = counts.get(("zigma_linear_fwd", "linear_ws"), 0)
-    if variant in ("default", "default_b32", "in_proj_halves_b32"):
+    if variant == "gate_in_in_proj_b32":
+        n_ws_silu = counts.get(("zigma_linear_fwd", "linear_ws_silu"), 0)
+        n_zact = sum(1 for fn, _, P in trace if fn == "zigma_selective_scan_fwd" and (P.flags & _lib.SCAN_Z_PREACTIVATED))
+        assert n_ws_silu == depth and n_ws == 0 and n_zact == depth and dt_in_scan == depth and gated == 2 * depth, (n_ws_silu, n_ws, n_zact, counts)
+    elif variant in ("default", "default_b32", "in_proj_halves_b32"):
         assert gated == 2 * depth, (gated, counts)          # out_proj + to_out, every block
         assert n_text == 2, (n_text, counts)                # no library GEMM on the text side either
         if variant == "default_b32":                        # every projection of the block loop on an own kernel: in_proj (weight-stationary) + out_proj + to_q + to_out

@@ -493,6 +493,46 @@ def test_scan_tok2_dt_proj_in_kernel_vs_oracle(Bsz, L, Di, R, use_perm, io):
     assert e2 < 5e-3, e2
 
 
+@pytest.mark.parametrize("Bsz,L,Di,R", [(2, 64, 128, 40), (3, 1024, 192, 48), (5, 48, 1280, 40)])
+def test_scan_tok2_dt_proj_in_kernel_preactivated_gate(Bsz, L, Di, R):
+    """dt_proj inside the scan together with ZIGMA_SCAN_Z_PREACTIVATED (round 5: the gate half of in_proj arrives as silu(z)): the kernel
+    multiplies by z as it finds it.  Against the oracle's UNGATED y times the same bf16 gate, and against the kernel's own result with the
+    raw z (the two differ by the bf16 rounding of silu(z) only)."""
+    from zigma_amd import _lib
+    from zigma_amd.selective_scan_interface import scan_raw
+    Nst = 16
+    bf = zo.bf16_round
+    rng = np.random.default_rng(Bsz * 77 + L + R)
+    u = bf(rng.standard_normal((Bsz, L, Di)).astype(np.float32))
+    z = bf(rng.standard_normal((Bsz, L, Di)).astype(np.float32))
+    zs = bf(zo.silu(z))
+    xd = bf(rng.standard_normal((Bsz, L, R + 2 * Nst)).astype(np.float32))
+    w = bf((rng.standard_normal((Di, R)) * R ** -0.5).astype(np.float32))
+    A = -np.exp(np.log(np.arange(1, Nst + 1, dtype=np.float32))[None].repeat(Di, 0) + 0.2 * rng.standard_normal((Di, Nst))).astype(np.float32)
+    D = (1 + 0.2 * rng.standard_normal(Di)).astype(np.float32)
+    db = (rng.standard_normal(Di) - 3.0).astype(np.float32)
+    perm = np.random.default_rng(5).permutation(L).astype(np.int64)
+    tdt = torch.bfloat16
+    ut, zt, zst, xt, wt = T(u, tdt), T(z, tdt), T(zs, tdt), T(xd, tdt), T(w, tdt)
+    pt = torch.from_numpy(perm).to(DEV).to(torch.int32)
+    Bv, Cv = xt[:, :, R:R + Nst].transpose(1, 2).unsqueeze(1), xt[:, :, R + Nst:].transpose(1, 2).unsqueeze(1)
+    y, y_raw = torch.empty(Bsz, L, Di, device=DEV, dtype=tdt), torch.empty(Bsz, L, Di, device=DEV, dtype=tdt)
+    scan_raw(ut.transpose(1, 2), None, T(A), Bv, Cv, T(D), zst.transpose(1, 2), T(db), True, out_z=y.transpose(1, 2),
+             z_row_index=pt, out_row_index=pt, want_out=False, dt_x=xt, dt_w=wt, z_preactivated=True)
+    assert _lib.last_kernel() == "scan_tok2_n16_dtproj"
+    scan_raw(ut.transpose(1, 2), None, T(A), Bv, Cv, T(D), zt.transpose(1, 2), T(db), True, out_z=y_raw.transpose(1, 2),
+             z_row_index=pt, out_row_index=pt, want_out=False, dt_x=xt, dt_w=wt)
+    delta = np.einsum("blr,dr->bdl", xd[:, :, :R].astype(np.float32), w.astype(np.float32))
+    ung = zo.selective_scan(u.transpose(0, 2, 1), delta, A, xd[:, :, R:R + Nst].transpose(0, 2, 1), xd[:, :, R + Nst:].transpose(0, 2, 1),
+                            D, None, db, True).transpose(0, 2, 1)                  # scan order, no gate
+    ref = ung * zs[:, perm]
+    e = rel_err(N(y)[:, perm], bf(ref))
+    e_raw = rel_err(N(y), N(y_raw))
+    print(f"dt_proj in kernel + pre-activated gate B={Bsz} L={L} Di={Di}: vs oracle {e:.2e}; vs the raw-z kernel {e_raw:.2e}")
+    assert np.isfinite(N(y)).all() and e < 1e-3, e
+    assert e_raw < 4e-3, e_raw
+
+
 def test_scan_dt_in_kernel_limits():
     """What the in-kernel dt_proj (zigma_scan_params_t.dt_x) refuses — the limits tok2_dtp_ok() states, each hit on its own: with dt_x
     set no other kernel serves the call, so the C side answers ZIGMA_ERR_UNSUPPORTED and the caller has to keep the dt_proj kernel."""
@@ -1026,6 +1066,34 @@ def test_linear_ws_kernel(M, K, N):
     xs = torch.zeros(M, K + 128, device=DEV, dtype=torch.bfloat16)          # rows of the input 128 elements further apart
     xs[:, :K] = x
     assert torch.equal(linear(xs[:, :K], w, weight_stationary=True), y)
+
+
+@pytest.mark.parametrize("M,K,N,col", [(65536, 640, 2560, 1280), (16384, 640, 1280, 640), (5632, 512, 1024, 256), (8192, 640, 512, 0)])
+def test_linear_ws_silu_epilogue(M, K, N, col):
+    """linear_ws_kernel<.., SL>: output columns >= silu_from_col leave as silu(.) of the fp32 accumulator (the pre-activated gate half of in_proj),
+    the columns below are bit-identical with the plain kernel; float64 reference on the same bf16 operands; run-to-run identity."""
+    from zigma_amd import _lib
+    from zigma_amd.linear import linear
+    g = torch.Generator(device="cpu").manual_seed(M + N + K + 1)
+    x = torch.randn(M, K, generator=g).to(DEV, torch.bfloat16)
+    w = (torch.randn(N, K, generator=g) * 2.0 * K ** -0.5).to(DEV, torch.bfloat16)
+    y0 = linear(x, w, weight_stationary=True)
+    y = linear(x, w, weight_stationary=True, silu_from_col=col)
+    assert _lib.last_kernel() == "linear_ws_silu"
+    assert torch.equal(y[:, :col], y0[:, :col])
+    rows = torch.randint(0, M, (1024,), generator=g).to(DEV)
+    rows[:6] = torch.tensor([0, 63, 64, 511, 512, M - 1], device=DEV)
+    acc = x[rows].double() @ w.double().T
+    ref = torch.nn.functional.silu(acc[:, col:])
+    got = y[rows][:, col:].double()
+    assert float((got - ref).norm() / ref.norm()) < 2.5e-3
+    assert torch.allclose(got, ref, rtol=1.6e-2, atol=1e-2)
+    # against silu applied to the ROUNDED product (what the scan's own gate computes from the bf16 z): one bf16 rounding apart
+    ref2 = torch.nn.functional.silu(y0[:, col:].float())
+    assert float((y[:, col:].float() - ref2).norm() / ref2.norm()) < 4e-3
+    assert torch.equal(linear(x, w, weight_stationary=True, silu_from_col=col), y)
+    with pytest.raises(RuntimeError):           # a wave's 64 features are all-or-nothing: whole 128-column groups only
+        linear(x, w, weight_stationary=True, silu_from_col=col + 64)
 
 
 def test_linear_ws_limits():

@@ -1,0 +1,122 @@
+"""Round-5 A/B in ONE process (interleaved rounds, HIP events): the round-4 library (tools/libzigma_base_r04.so, built from the
+round-4 sources) against the current one.
+  scan      headline shape (B=64, L=1024, Di=1280, N=16, R=40, bf16, zigzag tables), dt_proj + softplus inside the kernel:
+            r4 kernel | r5 kernel (step size in log2 units, D u as an fma) | r5 kernel with the pre-activated gate
+  in_proj   weight-stationary kernel on the in_proj shape: r4 | r5 plain | r5 with silu on the gate half
+  config 4  sequence-split scan (B=4, L=16384): r4 | r5 (priority rotation in both passes) | r5 with the rotation probed off
+Prints one JSON line and writes gpurun_out/r05_scan_ab.json."""
+import json, os, sys, torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from zigma_amd import _lib
+from zigma_amd.linear import linear
+from zigma_amd.selective_scan_interface import scan_raw
+
+BASE = os.path.join(ROOT, "tools", "libzigma_base_r04.so")
+NEW = _lib.LIB_PATH
+_handles = {}
+
+
+def use(path):
+    if path not in _handles:
+        _lib._lib, _lib.LIB_PATH = None, path
+        _handles[path] = _lib.lib()
+    _lib._lib, _lib.LIB_PATH = _handles[path], path
+
+
+dev, dt = "cuda", torch.bfloat16
+N, R, Di = 16, 40, 1280
+torch.manual_seed(0)
+
+
+def mk(B, L):
+    d = {}
+    d["xz"] = torch.randn(B, L, 2 * Di, device=dev, dtype=dt)
+    d["u"] = torch.randn(B, L, Di, device=dev, dtype=dt)
+    d["xdbl"] = torch.randn(B, L, R + 2 * N, device=dev, dtype=dt)
+    d["w"] = (R ** -0.5 * torch.randn(Di, R, device=dev)).to(dt)
+    d["db"] = torch.randn(Di, device=dev) - 3
+    d["A"] = -torch.exp(torch.log(torch.arange(1, N + 1, device=dev).float()) + 0.1 * torch.randn(Di, N, device=dev)).contiguous()
+    d["D"] = torch.randn(Di, device=dev)
+    d["perm"] = torch.randperm(L, device=dev).to(torch.int32)
+    d["Bv"] = d["xdbl"][:, :, R:R + N].transpose(1, 2).unsqueeze(1)
+    d["Cv"] = d["xdbl"][:, :, R + N:].transpose(1, 2).unsqueeze(1)
+    d["z"] = d["xz"][:, :, Di:].transpose(1, 2)
+    d["zs"] = torch.nn.functional.silu(d["xz"][:, :, Di:].float()).to(dt).transpose(1, 2)
+    d["delta"] = (0.5 * torch.rand(B, L, Di, device=dev)).to(dt)
+    return d
+
+
+h = mk(64, 1024)
+outs = {}
+
+
+def scan_dtp(name, lib, zact=False):
+    def f():
+        use(lib)
+        y = outs.setdefault(name, torch.empty(64, 1024, Di, device=dev, dtype=dt))
+        scan_raw(h["u"].transpose(1, 2), None, h["A"], h["Bv"], h["Cv"], h["D"], h["zs"] if zact else h["z"], h["db"], True,
+                 out_z=y.transpose(1, 2), z_row_index=h["perm"], out_row_index=h["perm"], want_out=False, dt_x=h["xdbl"], dt_w=h["w"],
+                 z_preactivated=zact)
+    return f
+
+
+# ---- config 4: sequence split
+c4 = mk(4, 16384)
+CH = 1024
+xc = torch.empty(4, Di, 16384 // CH, 2 * N, device=dev, dtype=torch.float32)
+
+
+def scan_c4(name, lib, flags=0):
+    def f():
+        use(lib)
+        y = outs.setdefault(name, torch.empty(4, 16384, Di, device=dev, dtype=dt))
+        scan_raw(c4["u"].transpose(1, 2), c4["delta"].transpose(1, 2), c4["A"], c4["Bv"], c4["Cv"], c4["D"], c4["z"], None, False,
+                 out_z=y.transpose(1, 2), z_row_index=c4["perm"], out_row_index=c4["perm"], want_out=False, x=xc, chunk_len=CH, _probe_flags=flags)
+    return f
+
+
+# ---- in_proj
+xin = torch.randn(65536, 640, device=dev, dtype=dt)
+win = (640 ** -0.5 * torch.randn(2560, 640, device=dev)).to(dt)
+o_in = torch.empty(65536, 2560, device=dev, dtype=dt)
+
+
+def inproj(lib, silu=False):
+    def f():
+        use(lib)
+        linear(xin, win, weight_stationary=True, out=o_in, silu_from_col=1280 if silu else None)
+    return f
+
+
+PR = 1 << _lib.SCAN_PROBE_PRIO_SHIFT
+groups = {
+    "scan": {"r4": scan_dtp("s_r4", BASE), "r5": scan_dtp("s_r5", NEW), "r5_zact": scan_dtp("s_r5z", NEW, True)},
+    "in_proj": {"r4": inproj(BASE), "r5": inproj(NEW), "r5_silu": inproj(NEW, True)},
+    "config4_split": {"r4": scan_c4("c_r4", BASE), "r5_rot": scan_c4("c_r5", NEW), "r5_norot": scan_c4("c_r5n", NEW, PR)},
+}
+res = {}
+for gname, fs in groups.items():
+    for f in fs.values():
+        f()
+    torch.cuda.synchronize()
+    times = {k: [] for k in fs}
+    for rnd in range(7):
+        for k, f in fs.items():
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(10):
+                f()
+            e1.record(); torch.cuda.synchronize()
+            times[k].append(e0.elapsed_time(e1) / 10 * 1e3)
+    res[gname] = {"us_median": {k: round(sorted(v)[len(v) // 2], 2) for k, v in times.items()}, "us_min": {k: round(min(v), 2) for k, v in times.items()}}
+rel = lambda a, b: float((a.float() - b.float()).norm() / b.float().norm())
+res["scan"]["rel_diff_r5_vs_r4"] = rel(outs["s_r5"], outs["s_r4"])
+res["scan"]["rel_diff_zact_vs_r4"] = rel(outs["s_r5z"], outs["s_r4"])
+res["config4_split"]["rel_diff_r5_vs_r4"] = rel(outs["c_r5"], outs["c_r4"])
+res["config4_split"]["rot_identical"] = bool(torch.equal(outs["c_r5"], outs["c_r5n"]))
+algo = 64 * 1024 * (4 * 2 * Di + 2 * 2 * N) + 4 * Di * (N + 2)
+res["scan"]["hbm_frac_formula"] = {k: round(algo / (v * 1e-6) / 8e12, 4) for k, v in res["scan"]["us_median"].items()}
+print(json.dumps(res))
+os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+json.dump(res, open(os.path.join(ROOT, "gpurun_out", "r05_scan_ab.json"), "w"), indent=1)

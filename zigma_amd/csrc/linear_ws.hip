@@ -15,7 +15,7 @@
 //   Tokens: slices of 64 tokens x 128 k (16 KB, global_load_lds_dwordx4, 16-byte slots XOR-swizzled by the row on the source side)
 //   through a ring of eight; ONE counted vmcnt + barrier per two slices; B fragments by ds_read_b128, one k-group ahead.
 //   Epilogue per tile: accumulators -> bf16 -> the wave's LDS tile -> 16-byte stores (64 FB contiguous bytes per token and wave).
-// Limits: bf16, no bias / activation / residual, k = 512 or 640, n % 256 == 0, m % 512 == 0.
+// Limits: bf16, no bias / residual, SiLU only on whole 128-column groups from silu_from_col on, k = 512 or 640, n % 256 == 0, m % 512 == 0.
 // FB is a template parameter: the 128-feature form (FB = 1: one MFMA per fragment read, k up to 1280 — out_proj / to_out shapes) was
 // instantiated, is bit-identical too and does NOT beat the tiled kernel: out_proj shape 102 vs 97 us, to_out shape 48 vs 45 us, its
 // MFMA-only loop 74.5 us against 65 at the FB = 2 rate (profiles/r04_h_linear_ws_probe_128_panels.jsonl) — not shipped.
@@ -93,7 +93,10 @@ __device__ __forceinline__ void mfma_f(f32x16 &acc, const WFrags<KG, FB> &w, con
 // PROBE (tools/linear_ws_probe.py; probe builds only): 0 = the kernel, 1 = no epilogue, 2 = default-policy stores instead of nt,
 // 3 = MFMAs only (no stream after the prologue, no barriers, no fragment reads, no epilogue), 4 = the fragment reads in front of the first MFMA
 // of the k-group instead of behind it
-template <int KG, int FB, int PROBE>
+// SL (round 5): output columns >= p.silu_from_col (a multiple of 64 FB, so a wave is all-or-nothing) leave as silu(.) — in_proj writing the
+// PRE-ACTIVATED gate half for the scan (ZIGMA_SCAN_Z_PREACTIVATED).  The 20 instructions per write chunk (4 values: -log2e *, v_exp, 1 +,
+// v_rcp, * x) are spread over the MFMA gaps 1 .. 3 of the chunk's k-group, the LDS write moves from gap 1 to gap 3.
+template <int KG, int FB, int PROBE, bool SL = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
 void linear_ws_kernel(const zigma_linear_params_t p, const int panels, const int ranges, const int tiles_per_xcd) {
     constexpr int NS = KG / 8;                           // slices per tile
@@ -109,6 +112,7 @@ void linear_ws_kernel(const zigma_linear_params_t p, const int panels, const int
     const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
     if (slot >= panels * ranges) return;
     const int panel = slot % panels, range = slot / panels;              // the `panels` workgroups of a range sit in adjacent slots
+    const bool do_silu = SL && panel * 128 * FB + wave * 32 * FB >= p.silu_from_col;       // (wave-uniform)
     const int t_lo = xcd * tiles_per_xcd + (range * tiles_per_xcd) / ranges;
     const int my_tiles = xcd * tiles_per_xcd + ((range + 1) * tiles_per_xcd) / ranges - t_lo;
     const unsigned lds_base = static_cast<unsigned>(reinterpret_cast<uintptr_t>((lds_ptr_t)(smem)));
@@ -182,6 +186,21 @@ void linear_ws_kernel(const zigma_linear_params_t p, const int panels, const int
         d[0] = pa[b][4 * q4]; d[1] = pa[b][4 * q4 + 1]; d[2] = pa[b][4 * q4 + 2]; d[3] = pa[b][4 * q4 + 3];
         asm volatile("" : "+v"(d[0]), "+v"(d[1]), "+v"(d[2]), "+v"(d[3]));     // (... and in front of this one)
     };
+    // silu(d) = d / (1 + exp2(-log2e d)) in three stages of four independent instructions each pair (one MFMA gap per stage)
+    auto silu_a = [&](const float (&d)[4], float (&e)[4]) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) e[i] = __builtin_amdgcn_exp2f(d[i] * -1.4426950408889634f);
+        asm volatile("" : "+v"(e[0]), "+v"(e[1]), "+v"(e[2]), "+v"(e[3]));
+    };
+    auto silu_b = [&](float (&e)[4]) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) e[i] = __builtin_amdgcn_rcpf(1.f + e[i]);
+        asm volatile("" : "+v"(e[0]), "+v"(e[1]), "+v"(e[2]), "+v"(e[3]));
+    };
+    auto silu_c = [&](float (&d)[4], const float (&e)[4]) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) d[i] *= e[i];
+    };
     auto wr_chunk_wr = [&](const int c, const float (&d)[4], const unsigned sw) {
         const int tb = (c >> 2) / FB, fb = (c >> 2) % FB, q4 = c & 3;
         const u32x2 pk = {pack_bf2(d[0], d[1]), pack_bf2(d[2], d[3])};
@@ -214,7 +233,7 @@ void linear_ws_kernel(const zigma_linear_params_t p, const int panels, const int
         constexpr bool EPI = decltype(epi_c)::value && PROBE != 1 && PROBE != 3;
         unsigned char *ot = ob + static_cast<int64_t>(t - 1) * kT * o_pitch;       // rows of the PREVIOUS tile
         u32x4 o;
-        float dch[4];
+        float dch[4], ech[4];
         // per-tile opaque copies of the three address bases: everything derived from them is computed where it is used
         unsigned ao = a_off, sw = scr_w, sr = scr_r;
         asm volatile("" : "+v"(ao), "+v"(sw), "+v"(sr));
@@ -266,7 +285,16 @@ void linear_ws_kernel(const zigma_linear_params_t p, const int panels, const int
                         if (rd_now) rd_chunk(o, r, sr);
                         if (wr_now) wr_chunk_rd(acc[PAR ^ 1], c, dch);
                     }
-                    if (mi == 1 && wr_now) wr_chunk_wr(c, dch, sw);             // ---- gap 1
+                    if constexpr (SL) {                  // ---- gaps 1 .. 3: the activation of the gate panels, then the write
+                        if (wr_now && do_silu) {
+                            if (mi == 1) silu_a(dch, ech);
+                            if (mi == 2) silu_b(ech);
+                            if (mi == 3) silu_c(dch, ech);
+                        }
+                        if (mi == NB - 1 && wr_now) wr_chunk_wr(c, dch, sw);
+                    } else {
+                        if (mi == 1 && wr_now) wr_chunk_wr(c, dch, sw);             // ---- gap 1
+                    }
                     if (dma) {                           // the last LPG gaps: FB = 2: gaps 2 and 3; FB = 1: gaps 0 and 1
                         const int first_l = FB == 2 ? mi - 2 : mi;
                         const int n_l = FB == 2 ? (mi >= 2 ? 1 : 0) : 1;
@@ -290,6 +318,10 @@ void linear_ws_kernel(const zigma_linear_params_t p, const int panels, const int
         for (int c = 0; c < NWC; ++c) {
             float d[4];
             wr_chunk_rd(acc[PAR], c, d);
+            if (SL && do_silu) {
+                float e[4];
+                silu_a(d, e); silu_b(e); silu_c(d, e);
+            }
             wr_chunk_wr(c, d, scr_w);
         }
         unsigned char *ot = ob + static_cast<int64_t>(t) * kT * o_pitch;
@@ -322,7 +354,8 @@ void linear_ws_kernel(const zigma_linear_params_t p, const int panels, const int
 
 // features per panel the weight-stationary kernel uses for the call (256), or 0 if it does not serve it
 static int linear_ws_panel(const zigma_linear_params_t &p) {
-    if (p.bias || p.residual || p.silu_from_col < p.n) return 0;
+    if (p.bias || p.residual) return 0;
+    if (p.silu_from_col < p.n && (p.silu_from_col < 0 || p.silu_from_col % 128 != 0)) return 0;     // a wave (64 features) is all-or-nothing
     if ((p.k != 512 && p.k != 640) || p.n % 256 != 0 || p.n > 8192 || p.m % 512 != 0) return 0;      // (instantiation set: k / 16 = 32, 40)
     if (p.out_row_stride % 8 != 0 || reinterpret_cast<uintptr_t>(p.out) % 16 != 0) return 0;
     const int pw = 256;
@@ -345,7 +378,9 @@ int launch_linear_ws(const zigma_linear_params_t &p, hipStream_t stream) {
     const int panels = p.n / pw, ranges = 32 / panels, tiles_per_xcd = static_cast<int>(p.m / 512);
     const int probe = (p.flags >> 16) & 7;
     const dim3 grid(256), block(256);
-#define ZIGMA_LWS(KG_, FB_, P_) hipLaunchKernelGGL((lws::linear_ws_kernel<KG_, FB_, P_>), grid, block, 0, stream, p, panels, ranges, tiles_per_xcd)
+    const bool sl = p.silu_from_col < p.n;
+#define ZIGMA_LWS(KG_, FB_, P_) do { if (sl) hipLaunchKernelGGL((lws::linear_ws_kernel<KG_, FB_, P_, true>), grid, block, 0, stream, p, panels, ranges, tiles_per_xcd); \
+                                     else hipLaunchKernelGGL((lws::linear_ws_kernel<KG_, FB_, P_, false>), grid, block, 0, stream, p, panels, ranges, tiles_per_xcd); } while (0)
 #ifdef ZIGMA_LINEAR4W_PROBES
 #define ZIGMA_LWS_K(KG_, FB_) { if (probe == 1) ZIGMA_LWS(KG_, FB_, 1); else if (probe == 2) ZIGMA_LWS(KG_, FB_, 2); else if (probe == 3) ZIGMA_LWS(KG_, FB_, 3); else if (probe == 4) ZIGMA_LWS(KG_, FB_, 4); else ZIGMA_LWS(KG_, FB_, 0); }
 #else
@@ -354,7 +389,7 @@ int launch_linear_ws(const zigma_linear_params_t &p, hipStream_t stream) {
     if (p.k == 640) ZIGMA_LWS_K(40, 2) else ZIGMA_LWS_K(32, 2)
 #undef ZIGMA_LWS_K
 #undef ZIGMA_LWS
-    set_last_kernel("linear_ws");
+    set_last_kernel(sl ? "linear_ws_silu" : "linear_ws");
     return check_launch();
 }
 

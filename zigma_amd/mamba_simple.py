@@ -28,6 +28,10 @@ IN_PROJ_WS = os.environ.get("ZIGMA_IN_PROJ_WS", "1") == "1"            # in_proj
 # ... from 8192 tokens on: 33.5 us against 41.5 (library) / 37.1 (tiled kernel) there, 52 / 72 / 59 at 16 384, 93 / 106 / 106 at 32 768; a tie at 4096
 # (tools/linear_ws_probe.py with M=...)
 IN_PROJ_WS_MIN_TOKENS = 8192
+# the SiLU of the gate in in_proj's epilogue (linear_ws_kernel<.., SL>: z leaves as silu(z)) instead of in the scan's (ZIGMA_SCAN_Z_PREACTIVATED):
+# 20 of the scan's 311 VALU instructions per tile-wave move into the GEMM's MFMA gaps; the gate is then rounded to bf16 once more than in the
+# reference (selective_scan_fwd_kernel.cuh:293 applies silu in fp32 to the bf16 z).  Measured in round 5: see there for the default.
+GATE_IN_IN_PROJ = os.environ.get("ZIGMA_GATE_IN_IN_PROJ", "0") == "1"
 
 
 def _int32_table(t, device):
@@ -214,11 +218,18 @@ class Mamba(nn.Module):
         batch, seqlen, _ = hidden_states.shape
         A, Dp, dtb = self._scan_consts("")
         st = self.scan_type
-        xz = self._proj(hidden_states, self.in_proj)                                  # (B, L, 2*Di) token-major
+        zact = (GATE_IN_IN_PROJ and not torch.is_grad_enabled() and IN_PROJ_WS and self.in_proj.bias is None and hidden_states.is_cuda
+                and hidden_states.dtype == torch.bfloat16 and (st == "v1" or st.startswith(("zigzagN", "hilbertN", "randomN")))
+                and self.d_state == 16 and seqlen % 16 == 0 and self.d_inner % 128 == 0 and batch * seqlen >= IN_PROJ_WS_MIN_TOKENS
+                and batch <= 65535 and linear_ws_eligible(hidden_states, self.in_proj.weight))
+        if zact:      # in_proj writes (x, silu(z)); the scan (hot kernel: 16-bit, 16 states, whole tiles) multiplies by the gate as it finds it
+            xz = linear(hidden_states, self.in_proj.weight, weight_stationary=True, silu_from_col=self.d_inner)
+        else:
+            xz = self._proj(hidden_states, self.in_proj)                              # (B, L, 2*Di) token-major
         fwd = lambda t, perm: mamba_inner_tok(t, self.conv1d.weight, self.conv1d.bias, self.x_proj.weight,
                                                self.dt_proj.weight, A, Dp, dtb,
                                                perm=perm, out_rows=self._out_rows if perm is self._perm else None,
-                                               delta_softplus=True)
+                                               delta_softplus=True, z_preactivated=zact)
         if st == "v1":
             y = fwd(xz, None)
         elif st == "v2":

@@ -537,7 +537,7 @@ def mamba_inner_fn_no_out_proj(xz, conv1d_weight, conv1d_bias, x_proj_weight, de
 
 def mamba_inner_tok(xz, conv1d_weight, conv1d_bias, x_proj_weight, delta_proj_weight, A, D, delta_bias, *,
                     perm=None, out_rows=None, B_proj_bias=None, C_proj_bias=None, delta_softplus=True, out=None,
-                    reset_period=0):
+                    reset_period=0, z_preactivated=False):
     """Token-major Mamba inner (no out_proj).
 
     xz: (batch, seqlen, 2*d_inner), token order, channel contiguous (the in_proj GEMM output as is).
@@ -550,14 +550,16 @@ def mamba_inner_tok(xz, conv1d_weight, conv1d_bias, x_proj_weight, delta_proj_we
           the inverse of perm; the caller passes out_rows = inverse(perm_rev) to reproduce exactly that.
     reset_period: > 0 = every batch row is a concatenation of independent sequences of that many steps (multiple of 16):
           conv window and SSM state restart there (the video temporal layers: batch = k, seqlen = b * t on strided views).
+    z_preactivated: the z half of xz already holds silu(z) (an in_proj epilogue wrote it; inference, 16-bit, d_state 16,
+          seqlen % 16 == 0 only — the hot kernel's ZIGMA_SCAN_Z_PREACTIVATED form).
     Returns y (batch, seqlen, d_inner) in token order = out_z of the reference's scan, before out_proj.
     """
     if xz.dim() != 3 or xz.stride(2) != 1:
         raise RuntimeError("xz must be (batch, seqlen, 2*d_inner) with contiguous channels")
     if torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in (
             xz, conv1d_weight, conv1d_bias, x_proj_weight, delta_proj_weight, A, D, delta_bias)):
-        if B_proj_bias is not None or C_proj_bias is not None or not delta_softplus or out is not None:
-            raise NotImplementedError("differentiable mamba_inner_tok: no B/C projection bias, softplus on, no out=")
+        if B_proj_bias is not None or C_proj_bias is not None or not delta_softplus or out is not None or z_preactivated:
+            raise NotImplementedError("differentiable mamba_inner_tok: no B/C projection bias, softplus on, no out=, no pre-activated gate")
         return mamba_inner_tok_train(xz, conv1d_weight, conv1d_bias, x_proj_weight, delta_proj_weight, A, D, delta_bias,
                                      perm=perm, out_rows=out_rows, reset_period=reset_period)
     Bsz, L, C2 = xz.shape
@@ -578,7 +580,7 @@ def mamba_inner_tok(xz, conv1d_weight, conv1d_bias, x_proj_weight, delta_proj_we
         else:
             x_dbl = F.linear(u, x_proj_weight)                           # (B, L, R + 2N)   GEMM
     return _inner_tok_tail(u, x_dbl, z_half, delta_proj_weight, A, D, delta_bias, perm, out_rows, B_proj_bias, C_proj_bias,
-                           delta_softplus, out, reset_period, False)
+                           delta_softplus, out, reset_period, z_preactivated)
 
 
 def _inner_tok_tail(u, x_dbl, z_half, delta_proj_weight, A, D, delta_bias, perm, out_rows, B_proj_bias, C_proj_bias,
@@ -587,7 +589,7 @@ def _inner_tok_tail(u, x_dbl, z_half, delta_proj_weight, A, D, delta_bias, perm,
     Bsz, L, Di = u.shape
     R = delta_proj_weight.shape[1]
     N = A.shape[1]
-    in_scan = (DT_PROJ_IN_SCAN and delta_softplus and not z_preactivated
+    in_scan = (DT_PROJ_IN_SCAN and delta_softplus
                and dt_in_scan_eligible(u, x_dbl, delta_proj_weight, reset_period, out, dstate=N, z=z_half)
                and B_proj_bias is None and C_proj_bias is None and not split_chunk_len(Bsz, Di, L, reset_period))
     if in_scan:                      # dt_proj + bias + softplus inside the scan kernel's tile prologue: delta is never materialised
