@@ -543,8 +543,8 @@ def test_scan_dt_in_kernel_limits():
     wt = torch.randn(Di, R, device=DEV).bfloat16()
     A = -torch.rand(Di, Nst, device=DEV)
     Bv, Cv = xt[:, :, R:R + Nst].transpose(1, 2).unsqueeze(1), xt[:, :, R + Nst:].transpose(1, 2).unsqueeze(1)
-    ok = lambda **kw: scan_raw(ut.transpose(1, 2), None, A, Bv, Cv, None, ut.transpose(1, 2), None, True, want_out=False,
-                               **{"dt_x": xt, "dt_w": wt, **kw})
+    ok = lambda **kw: scan_raw(ut.transpose(1, 2), None, A, Bv, Cv, None, ut.transpose(1, 2), None, True,
+                               **{"dt_x": xt, "dt_w": wt, "want_out": False, **kw})
     ok()                                    # the base case is served (so every refusal below is the one limit it names)
     assert dt_in_scan_eligible(ut, xt, wt, dstate=Nst, z=ut)
     with pytest.raises(RuntimeError):       # delta=None without the pair
