@@ -155,14 +155,16 @@ def test_bench_block_path_vs_reference(variant, monkeypatch):
         n_zact = sum(1 for fn, _, P in trace if fn == "zigma_selective_scan_fwd" and (P.flags & _lib.SCAN_Z_PREACTIVATED))
         assert n_ws_silu == depth and n_ws == 0 and n_zact == depth and dt_in_scan == depth and gated == 2 * depth, (n_ws_silu, n_ws, n_zact, counts)
     elif variant in ("default", "default_b32", "in_proj_halves_b32"):
-        assert gated == 2 * depth, (gated, counts)          # out_proj + to_out, every block
+        # out_proj + to_out carry their gated adds, every block; at 16 384 tokens (round 5) out_proj's add rides in the next norm kernel
+        # instead: below the 4-wave kernel's tile floor the library product + that add are faster than the fused 8-wave call
+        assert gated == (depth if variant == "default" else 2 * depth), (gated, counts)
         assert n_text == 2, (n_text, counts)                # no library GEMM on the text side either
         if variant == "default_b32":                        # every projection of the block loop on an own kernel: in_proj (weight-stationary) + out_proj + to_q + to_out
             assert n_ws == depth and n_in_halves == 0 and n_lin == 4 * depth + 2, (n_ws, n_in_halves, n_lin, counts)
         elif variant == "in_proj_halves_b32":               # ... with in_proj as two half-width launches of the tiled kernel
             assert n_ws == 0 and n_in_halves == 2 * depth and n_lin == 5 * depth + 2, (n_in_halves, n_lin, counts)
         else:
-            assert n_ws == depth and n_lin >= 3 * depth + 2    # (at 16 384 tokens in_proj is on the weight-stationary kernel already; to_q stays on the library: too few tiles for the 4-wave kernel)
+            assert n_ws == 2 * depth and n_lin == 3 * depth + 2, (n_ws, n_lin, counts)    # (at 16 384 tokens in_proj AND to_q are on the weight-stationary kernel, + to_out; out_proj is the library's)
     elif variant == "unfused_out_proj":
         assert gated == depth, (gated, counts)              # to_out only
     elif variant == "linear_all":

@@ -799,18 +799,21 @@ def test_graphed_forward_matches_eager_and_sampler_runs_on_it():
         gf(x[:1], t[:1], y[:1])
 
 
-@pytest.mark.parametrize("M,K,Nn", [(1, 256, 72), (300, 1280, 72), (4096, 1536, 80), (257, 512, 96), (64, 256, 40), (16384, 1280, 72)])
+@pytest.mark.parametrize("M,K,Nn", [(1, 256, 72), (300, 1280, 72), (4096, 1536, 80), (257, 512, 96), (64, 256, 40), (16384, 1280, 72), (8192, 1536, 80),
+                                    (8192, 1280, 72), (1000, 1024, 96), (16352, 1536, 33), (32768, 1536, 80), (512, 2048, 72)])
 def test_x_proj_kernel_vs_oracle(M, K, Nn):
-    """x_dbl = u @ W_x^T with the read-bound MFMA kernel vs float64 numpy on the same bf16 operands (output rounded to bf16)."""
+    """x_dbl = u @ W_x^T with the read-bound MFMA kernel (from 16 384 tokens on, or k > 1536) / its split-K form for few tokens (round 5) vs
+    float64 numpy on the same bf16 operands (output rounded to bf16); run-to-run identity of the split-K sum."""
     from zigma_amd import _lib
     from zigma_amd.selective_scan_interface import x_proj, x_proj_eligible
     rng = np.random.default_rng(M + K)
     u = zo.bf16_round(rng.standard_normal((M, K)).astype(np.float32))
     w = zo.bf16_round((rng.standard_normal((Nn, K)) * K ** -0.5).astype(np.float32))
     ut, wt = T(u, torch.bfloat16), T(w, torch.bfloat16)
-    assert x_proj_eligible(ut, wt) == (M >= 16384)      # (the policy leaves small token counts to the library; the kernel takes them)
+    assert x_proj_eligible(ut, wt) == (M >= 16384 or (M >= 256 and K <= 1536))      # (the policy leaves tiny token counts to the library; the kernel takes them)
     out = x_proj(ut, wt)
-    assert _lib.last_kernel() == "x_proj_mfma" and out.shape == (M, Nn)
+    assert _lib.last_kernel() == ("x_proj_splitk" if M < 16384 and K <= 1536 else "x_proj_mfma") and out.shape == (M, Nn)
+    assert torch.equal(x_proj(ut, wt), out)
     ref = zo.bf16_round((u.astype(np.float64) @ w.astype(np.float64).T).astype(np.float32))
     assert rel_err(N(out), ref) < 3e-3 and np.allclose(N(out), ref, rtol=2e-2, atol=2e-2)
 

@@ -15,7 +15,8 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from .linear import gated_residual_eligible, linear, linear_eligible, linear_ws_eligible
+from . import linear as _zl
+from .linear import gated_residual_eligible, linear, linear_eligible, linear_ws_eligible, routes_to_4w
 from .selective_scan_interface import mamba_inner_tok
 from .wgrad import linear_train
 
@@ -28,9 +29,12 @@ IN_PROJ_WS = os.environ.get("ZIGMA_IN_PROJ_WS", "1") == "1"            # in_proj
 # ... from 8192 tokens on: 33.5 us against 41.5 (library) / 37.1 (tiled kernel) there, 52 / 72 / 59 at 16 384, 93 / 106 / 106 at 32 768; a tie at 4096
 # (tools/linear_ws_probe.py with M=...)
 IN_PROJ_WS_MIN_TOKENS = 8192
+# in_proj of the wider models (k >= this: E = 768 of the reference's shipped yamls, config/model/zigzag8_b1_pe2.yaml:7-8) as ONE launch of the tiled kernel; 0: off
+IN_PROJ_ONE_LAUNCH_K = int(os.environ.get("ZIGMA_IN_PROJ_ONE_LAUNCH_K", "704"))
 # the SiLU of the gate in in_proj's epilogue (linear_ws_kernel<.., SL>: z leaves as silu(z)) instead of in the scan's (ZIGMA_SCAN_Z_PREACTIVATED):
 # 20 of the scan's 311 VALU instructions per tile-wave move into the GEMM's MFMA gaps; the gate is then rounded to bf16 once more than in the
 # reference (selective_scan_fwd_kernel.cuh:293 applies silu in fp32 to the bf16 z).  Measured in round 5: see there for the default.
+OUT_PROJ_FUSE_NEEDS_4W = os.environ.get("ZIGMA_OUT_PROJ_FUSE_NEEDS_4W", "1") == "1"
 GATE_IN_IN_PROJ = os.environ.get("ZIGMA_GATE_IN_IN_PROJ", "0") == "1"
 
 
@@ -175,7 +179,11 @@ class Mamba(nn.Module):
         if torch.is_grad_enabled() or not residual.is_cuda or residual.dtype != torch.bfloat16 or residual.dim() != 3:
             return False
         y = torch.empty(residual.shape[0], residual.shape[1], self.d_inner, device="meta", dtype=residual.dtype)   # shape / dtype stand-in
-        return (residual.shape[1] * residual.shape[0] >= 16384 and lin.weight.dtype == torch.bfloat16 and self.d_inner % 64 == 0
+        # (round 5: only where the 4-wave kernel takes the product — below its 256-tile floor the fused call runs on the 8-wave kernel, 48 us at
+        # 16 384 tokens against 34 for the library + the add inside the next norm kernel, profiles/r05_b_shapes_probe.jsonl)
+        tokens = residual.shape[1] * residual.shape[0]
+        return (tokens >= 16384 and (routes_to_4w(tokens, lin.weight.shape[0], self.d_inner) or not OUT_PROJ_FUSE_NEEDS_4W or _zl.LINEAR_POLICY == "all")
+                and lin.weight.dtype == torch.bfloat16 and self.d_inner % 64 == 0
                 and lin.weight.shape[0] % 128 == 0 and gated_residual_eligible(y, residual, gate)
                 and (lin.bias is None or lin.bias.dtype == torch.bfloat16))
 
@@ -286,6 +294,13 @@ class Mamba(nn.Module):
         if IN_PROJ_WS and lin.bias is None and x.shape[:-1].numel() >= IN_PROJ_WS_MIN_TOKENS and linear_ws_eligible(x, lin.weight):
             # ONE launch, W_in panels resident in registers, only the tokens stream (half the L2 -> LDS bytes of the tiled kernel)
             return linear(x, lin.weight, weight_stationary=True)
+        tokens = x.shape[:-1].numel()
+        if (IN_PROJ_ONE_LAUNCH_K and lin.bias is None and x.shape[-1] >= IN_PROJ_ONE_LAUNCH_K and n >= 2048 and tokens >= IN_PROJ_WS_MIN_TOKENS
+                and routes_to_4w(tokens, n, x.shape[-1]) and linear_eligible(x, lin.weight, None, prefer_own=True)):
+            # widths the weight-stationary kernel does not hold (E = 768: the panel would be 384 registers per lane): ONE launch of the 4-wave
+            # tiled kernel — 49 / 71 / 139 / 268 us at 8192 / 16 384 / 32 768 / 65 536 tokens against 60 / 72 / 137 / 263 (library) and
+            # 58 / 93 / 141 / 275 as two half-width launches (profiles/r05_b_shapes_probe.jsonl)
+            return linear(x, lin.weight)
         if (IN_PROJ_SPLIT and lin.bias is None and n % 512 == 0 and n >= 2048 and x.dim() == 3
                 and linear_eligible(x, lin.weight[:n // 2], None, prefer_own=True) and x.shape[0] * x.shape[1] >= IN_PROJ_SPLIT_MIN_TOKENS):
             # in_proj as TWO launches of the own 4-wave kernel, one per half of the output columns, into one (B, L, 2 d_inner) buffer:

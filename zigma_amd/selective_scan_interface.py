@@ -188,11 +188,12 @@ def scan_raw(u, delta, A, B, C, D=None, z=None, delta_bias=None, delta_softplus=
 
 
 def x_proj_eligible(u, weight):
-    """limits of zigma_x_proj_fwd: bf16, n <= 96, k % 256 == 0, 16-byte aligned contiguous rows; and enough tokens to fill the
-    chip — a workgroup streams 256 token rows over the whole K, so below ~64 workgroups the kernel is latency-bound (config 5:
-    8192 tokens = 32 workgroups took 41 us, profiles/r02_c_cfg5_kernel_stats.csv) and the library's tiled GEMM is faster"""
+    """limits of zigma_x_proj_fwd: bf16, n <= 96, k % 256 == 0, 16-byte aligned contiguous rows.  From 16 384 tokens on a workgroup streams
+    256 token rows over the whole K; below, K is split over the waves of 32-token workgroups (x_proj_splitk_kernel, round 5: the streaming
+    form was 32 workgroups and 31 us at 8192 tokens against 21 for the library), which needs k <= 1536."""
+    tokens = u.numel() // u.shape[-1]
     return (u.is_cuda and u.dtype == torch.bfloat16 and weight.dtype == torch.bfloat16 and u.is_contiguous()
-            and u.numel() // u.shape[-1] >= 16384
+            and (tokens >= 16384 or (tokens >= 256 and weight.shape[1] <= 1536))
             and weight.shape[0] <= 96 and weight.shape[1] % 256 == 0 and weight.stride(1) == 1 and weight.stride(0) % 8 == 0
             and u.data_ptr() % 16 == 0 and weight.data_ptr() % 16 == 0)
 
