@@ -1037,7 +1037,7 @@ def test_linear4w_kernel(M, K, N, monkeypatch):
 
 
 @pytest.mark.parametrize("M,K,N", [(65536, 640, 2560), (65536, 640, 512), (32768, 640, 2560), (4096, 640, 8192), (5632, 512, 1024), (512 * 43, 512, 256),
-                                   (16384, 640, 1280)])
+                                   (16384, 640, 1280), (8192, 1280, 640), (16384, 1536, 768), (65536, 1280, 640), (512 * 11, 1536, 128), (8192, 1536, 768)])
 def test_linear_ws_kernel(M, K, N):
     """The weight-stationary projection kernel (csrc/linear_ws.hip; in_proj of the default path, reference mamba_simple.py:290-294): every
     output of sampled rows against float64 on the same bf16 operands; the WHOLE result bit-identical with the tiled kernel (same MFMA, same
@@ -1050,7 +1050,8 @@ def test_linear_ws_kernel(M, K, N):
     w = (torch.randn(N, K, generator=g) * K ** -0.5).to(DEV, torch.bfloat16)
     assert linear_ws_eligible(x, w)
     y = linear(x, w, weight_stationary=True)
-    assert _lib.last_kernel() == "linear_ws" and y.shape == (M, N)
+    kname = "linear_ws" if K <= 640 else "linear_ws_128"          # (k = 1280 / 1536: 128-feature panels, one 32-feature block per wave; round 5)
+    assert _lib.last_kernel() == kname and y.shape == (M, N)
     rows = torch.randint(0, M, (1024,), generator=g).to(DEV)
     rows[:6] = torch.tensor([0, 63, 64, 511, 512, M - 1], device=DEV)
     ref = x[rows].double() @ w.double().T
@@ -1064,7 +1065,7 @@ def test_linear_ws_kernel(M, K, N):
         assert torch.equal(linear(x, w, weight_stationary=True), y)
     wide = torch.zeros(M, N + 256, device=DEV, dtype=torch.bfloat16)
     linear(x, w, out=wide[:, 128:128 + N], weight_stationary=True)
-    assert _lib.last_kernel() == "linear_ws"
+    assert _lib.last_kernel() == kname
     assert torch.equal(wide[:, 128:128 + N], y) and float(wide[:, :128].abs().max()) == 0 and float(wide[:, 128 + N:].abs().max()) == 0
     xs = torch.zeros(M, K + 128, device=DEV, dtype=torch.bfloat16)          # rows of the input 128 elements further apart
     xs[:, :K] = x

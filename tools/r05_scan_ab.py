@@ -89,10 +89,23 @@ def inproj(lib, silu=False):
     return f
 
 
+h16 = mk(16, 1024)
+
+
+def scan_b16(name, lib):
+    def f():
+        use(lib)
+        y = outs.setdefault(name, torch.empty(16, 1024, Di, device=dev, dtype=dt))
+        scan_raw(h16["u"].transpose(1, 2), None, h16["A"], h16["Bv"], h16["Cv"], h16["D"], h16["z"], h16["db"], True,
+                 out_z=y.transpose(1, 2), z_row_index=h16["perm"], out_row_index=h16["perm"], want_out=False, dt_x=h16["xdbl"], dt_w=h16["w"])
+    return f
+
+
 PR = 1 << _lib.SCAN_PROBE_PRIO_SHIFT
 groups = {
     "scan": {"r4": scan_dtp("s_r4", BASE), "r5": scan_dtp("s_r5", NEW), "r5_zact": scan_dtp("s_r5z", NEW, True)},
     "in_proj": {"r4": inproj(BASE), "r5": inproj(NEW), "r5_silu": inproj(NEW, True)},
+    "scan_b16": {"r4": scan_b16("b_r4", BASE), "r5": scan_b16("b_r5", NEW)},
     "config4_split": {"r4": scan_c4("c_r4", BASE), "r5_rot": scan_c4("c_r5", NEW), "r5_norot": scan_c4("c_r5n", NEW, PR)},
 }
 res = {}

@@ -15,7 +15,8 @@
 //   Tokens: slices of 64 tokens x 128 k (16 KB, global_load_lds_dwordx4, 16-byte slots XOR-swizzled by the row on the source side)
 //   through a ring of eight; ONE counted vmcnt + barrier per two slices; B fragments by ds_read_b128, one k-group ahead.
 //   Epilogue per tile: accumulators -> bf16 -> the wave's LDS tile -> 16-byte stores (64 FB contiguous bytes per token and wave).
-// Limits: bf16, no bias / residual, SiLU only on whole 128-column groups from silu_from_col on, k = 512 or 640, n % 256 == 0, m % 512 == 0.
+// Limits: bf16, no bias / residual, SiLU only on whole 128-column groups from silu_from_col on; k = 512 or 640 with n % 256 == 0, or (FB = 1) k = 1280 / 1536
+// with n % 128 == 0; m % 512 == 0.
 // FB is a template parameter: the 128-feature form (FB = 1: one MFMA per fragment read, k up to 1280 — out_proj / to_out shapes) was
 // instantiated, is bit-identical too and does NOT beat the tiled kernel: out_proj shape 102 vs 97 us, to_out shape 48 vs 45 us, its
 // MFMA-only loop 74.5 us against 65 at the FB = 2 rate (profiles/r04_h_linear_ws_probe_128_panels.jsonl) — not shipped.
@@ -352,13 +353,16 @@ void linear_ws_kernel(const zigma_linear_params_t p, const int panels, const int
 
 }  // namespace lws
 
-// features per panel the weight-stationary kernel uses for the call (256), or 0 if it does not serve it
+// features per panel the weight-stationary kernel uses for the call (256: k = 512 / 640, two 32-feature blocks per wave; 128: k = 1280 / 1536, one
+// block per wave — the out_proj shapes at serving-size token counts, round 5), or 0 if it does not serve it
 static int linear_ws_panel(const zigma_linear_params_t &p) {
     if (p.bias || p.residual) return 0;
-    if (p.silu_from_col < p.n && (p.silu_from_col < 0 || p.silu_from_col % 128 != 0)) return 0;     // a wave (64 features) is all-or-nothing
-    if ((p.k != 512 && p.k != 640) || p.n % 256 != 0 || p.n > 8192 || p.m % 512 != 0) return 0;      // (instantiation set: k / 16 = 32, 40)
+    const bool narrow = p.k == 1280 || p.k == 1536;
+    if (!narrow && p.k != 512 && p.k != 640) return 0;                                                // (instantiation set: k / 16 = 32, 40 | 80, 96)
+    const int pw = narrow ? 128 : 256;
+    if (p.silu_from_col < p.n && (narrow || p.silu_from_col < 0 || p.silu_from_col % 128 != 0)) return 0;     // a wave (64 features) is all-or-nothing
+    if (p.n % pw != 0 || p.n > 8192 || p.m % 512 != 0) return 0;
     if (p.out_row_stride % 8 != 0 || reinterpret_cast<uintptr_t>(p.out) % 16 != 0) return 0;
-    const int pw = 256;
     const int panels = p.n / pw;
     if (panels > 32) return 0;
     const int ranges = 32 / panels;
@@ -386,10 +390,15 @@ int launch_linear_ws(const zigma_linear_params_t &p, hipStream_t stream) {
 #else
 #define ZIGMA_LWS_K(KG_, FB_) { if (probe) return ZIGMA_ERR_UNSUPPORTED; ZIGMA_LWS(KG_, FB_, 0); }
 #endif
-    if (p.k == 640) ZIGMA_LWS_K(40, 2) else ZIGMA_LWS_K(32, 2)
+    if (p.k == 640) ZIGMA_LWS_K(40, 2) else if (p.k == 512) ZIGMA_LWS_K(32, 2)
+    else {      // one 32-feature block per wave (128-feature panels): k = 1280 / 1536
+        if (probe || sl) return ZIGMA_ERR_UNSUPPORTED;
+        if (p.k == 1280) hipLaunchKernelGGL((lws::linear_ws_kernel<80, 1, 0, false>), grid, block, 0, stream, p, panels, ranges, tiles_per_xcd);
+        else hipLaunchKernelGGL((lws::linear_ws_kernel<96, 1, 0, false>), grid, block, 0, stream, p, panels, ranges, tiles_per_xcd);
+    }
 #undef ZIGMA_LWS_K
 #undef ZIGMA_LWS
-    set_last_kernel(sl ? "linear_ws_silu" : "linear_ws");
+    set_last_kernel(sl ? "linear_ws_silu" : pw == 128 ? "linear_ws_128" : "linear_ws");
     return check_launch();
 }
 

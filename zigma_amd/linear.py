@@ -58,14 +58,16 @@ LINEAR_WS_FLAG = 0x4000          # zigma_linear_params_t.flags: ZIGMA_LINEAR_WS 
 
 
 def linear_ws_eligible(x, weight, bias=None):
-    """limits of the weight-stationary kernel (csrc/linear_ws.hip: a W panel of 256 features lives in the registers of a workgroup, only the
-    tokens stream): bf16, no bias, k = 512 or 640, n % 256 == 0 (<= 8192), tokens % 512 == 0, x rows a multiple of 128 elements apart — on
-    top of linear_eligible's alignment rules."""
+    """limits of the weight-stationary kernel (csrc/linear_ws.hip: a W panel lives in the registers of a workgroup, only the tokens stream): bf16, no
+    bias; k = 512 or 640 with 256-feature panels (n % 256 == 0), or k = 1280 / 1536 with 128-feature panels (n % 128 == 0: the out_proj shapes, used
+    below the tiled 4-wave kernel's floor); n <= 8192, tokens % 512 == 0 and enough of them for every workgroup of an XCD to own a tile, x rows a multiple
+    of 128 elements apart — on top of linear_eligible's alignment rules."""
     if bias is not None or not linear_eligible(x, weight, None, prefer_own=True):
         return False
     n, k = weight.shape
     m = x.numel() // k
-    return k in (512, 640) and n % 256 == 0 and n <= 8192 and m % 512 == 0 and m // 512 >= 32 // (n // 256) and x.stride(-2) % 128 == 0
+    pw = 256 if k in (512, 640) else 128 if k in (1280, 1536) else 0
+    return pw > 0 and n % pw == 0 and n <= 8192 and m % 512 == 0 and m // 512 >= 32 // (n // pw) and x.stride(-2) % 128 == 0
 
 
 def linear(x, weight, bias=None, silu_from_col=None, out=None, _probe_flags=0, residual=None, gate=None, weight_stationary=False):

@@ -34,6 +34,8 @@ IN_PROJ_ONE_LAUNCH_K = int(os.environ.get("ZIGMA_IN_PROJ_ONE_LAUNCH_K", "704"))
 # the SiLU of the gate in in_proj's epilogue (linear_ws_kernel<.., SL>: z leaves as silu(z)) instead of in the scan's (ZIGMA_SCAN_Z_PREACTIVATED):
 # 20 of the scan's 311 VALU instructions per tile-wave move into the GEMM's MFMA gaps; the gate is then rounded to bf16 once more than in the
 # reference (selective_scan_fwd_kernel.cuh:293 applies silu in fp32 to the bf16 z).  Measured in round 5: see there for the default.
+# out_proj (k = 1280 / 1536) on the weight-stationary kernel's 128-feature-panel form below the tiled 4-wave kernel's token floor (round 5)
+OUT_PROJ_WS_MAX_TOKENS = int(os.environ.get("ZIGMA_OUT_PROJ_WS_MAX_TOKENS", "32768"))
 OUT_PROJ_FUSE_NEEDS_4W = os.environ.get("ZIGMA_OUT_PROJ_FUSE_NEEDS_4W", "1") == "1"
 GATE_IN_IN_PROJ = os.environ.get("ZIGMA_GATE_IN_IN_PROJ", "0") == "1"
 
@@ -291,7 +293,8 @@ class Mamba(nn.Module):
         if linear_eligible(x, lin.weight, lin.bias):
             return linear(x, lin.weight, lin.bias)
         n = lin.weight.shape[0]
-        if IN_PROJ_WS and lin.bias is None and x.shape[:-1].numel() >= IN_PROJ_WS_MIN_TOKENS and linear_ws_eligible(x, lin.weight):
+        if (IN_PROJ_WS and lin.bias is None and x.shape[:-1].numel() >= IN_PROJ_WS_MIN_TOKENS and linear_ws_eligible(x, lin.weight)
+                and (lin.weight.shape[1] <= 640 or x.shape[:-1].numel() < OUT_PROJ_WS_MAX_TOKENS)):
             # ONE launch, W_in panels resident in registers, only the tokens stream (half the L2 -> LDS bytes of the tiled kernel)
             return linear(x, lin.weight, weight_stationary=True)
         tokens = x.shape[:-1].numel()

@@ -282,7 +282,7 @@ class Pending:
 # pre-attention add + norm 68 -> 47, and with to_out's gated add: to_out 63 -> 78, pre-mixer add + norm 119 -> 102 — time moves from
 # the HBM-bound norm kernels into the projection epilogues, the forward is 0.1-0.3 % faster.
 TEXT_PROJ_OWN = os.environ.get("ZIGMA_TEXT_PROJ_OWN", "1") == "1"
-TO_Q_WS_MAX_TOKENS = 16384
+TO_Q_WS_MAX_TOKENS = int(os.environ.get("ZIGMA_TO_Q_WS_MAX_TOKENS", "16384"))
 TO_Q_WS = os.environ.get("ZIGMA_TO_Q_WS", "0") == "1"      # to_q on the weight-stationary kernel (A/B knob: a tie stand-alone)   # y_embedder and the batched K / V projection of all blocks (B x 77 text rows) on zigma_linear_fwd, rows padded to 256
 
 
