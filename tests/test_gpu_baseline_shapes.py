@@ -164,12 +164,12 @@ def test_bench_block_path_vs_reference(variant, monkeypatch):
         elif variant == "in_proj_halves_b32":               # ... with in_proj as two half-width launches of the tiled kernel
             assert n_ws == 0 and n_in_halves == 2 * depth and n_lin == 5 * depth + 2, (n_in_halves, n_lin, counts)
         else:
-            # at 16 384 tokens in_proj AND to_q are on the weight-stationary kernel, out_proj (unfused) on its 128-feature-panel form, + to_out:
-            # every projection of the block loop on an own kernel here too (round 5)
+            # at 16 384 tokens in_proj is on the weight-stationary kernel, out_proj (unfused) on its 128-feature-panel form, + to_out
             import zigma_amd.mamba_simple as zms
             n_ws128 = counts.get(("zigma_linear_fwd", "linear_ws_128"), 0)
             want128 = depth if zms.OUT_PROJ_WS_MAX_TOKENS > Bsz * 1024 else 0
-            assert n_ws == 2 * depth and n_ws128 == want128 and n_lin == 3 * depth + want128 + 2, (n_ws, n_ws128, n_lin, counts)
+            n_toq_ws = depth if mz.TO_Q_WS_MAX_TOKENS >= Bsz * 1024 else 0       # (8192: to_q stays the library's at 16 384 tokens, the forward is faster so)
+            assert n_ws == depth + n_toq_ws and n_ws128 == want128 and n_lin == 2 * depth + n_toq_ws + want128 + 2, (n_ws, n_ws128, n_lin, counts)
     elif variant == "unfused_out_proj":
         assert gated == depth, (gated, counts)              # to_out only
     elif variant == "linear_all":
@@ -202,7 +202,8 @@ def test_no_text_block_path_trace_and_oracle(monkeypatch):
     m = m.to(DEV).eval()
     Bsz = 32
     gen = torch.Generator().manual_seed(5)
-    x, t = torch.randn(Bsz, 4, 32, 32, generator=gen), torch.rand(Bsz, generator=gen)
+    x, t = torch.randn(16, 4, 32, 32, generator=gen), torch.rand(16, generator=gen)          # (the 16 samples this test has always used ...)
+    x, t = torch.cat([x, torch.randn(16, 4, 32, 32, generator=gen)]), torch.cat([t, torch.rand(16, generator=gen)])      # ... + 16 more for the token floor
     xb, tb = x.to(DEV).bfloat16(), t.to(DEV).bfloat16()
     trace = []
     monkeypatch.setattr(_lib, "TRACE", trace)
@@ -222,7 +223,7 @@ def test_no_text_block_path_trace_and_oracle(monkeypatch):
     assert _trace_counts(trace2)[1] == 0
     e_fu = rel_err(N(out), N(out_u))
     om = zo.ZigMaOracle(state, cfg)
-    rows = [0, Bsz - 1]
+    rows = [0, 15]
     ref = om.forward(N(xb.float())[rows], N(tb.float())[rows], None)
     e_or, e_or_u = rel_err(N(out)[rows], ref), rel_err(N(out_u)[rows], ref)
     print(f"no-text blocks, B={Bsz}: fused vs unfused {e_fu:.3e}; vs fp32 oracle: fused {e_or:.3e}, unfused {e_or_u:.3e}")

@@ -101,11 +101,45 @@ def scan_b16(name, lib):
     return f
 
 
+# ---- B = 8: sequence split as the model sizes it (160 (sample, slab) pairs -> chunks for ~768 workgroups)
+from zigma_amd.selective_scan_interface import split_chunk_len
+h8 = mk(8, 1024)
+CH8 = split_chunk_len(8, Di, 1024)
+xc8 = torch.empty(8, Di, -(-1024 // CH8), 2 * N, device=dev, dtype=torch.float32)
+
+
+def scan_b8(name, lib, flags=0):
+    def f():
+        use(lib)
+        y = outs.setdefault(name, torch.empty(8, 1024, Di, device=dev, dtype=dt))
+        scan_raw(h8["u"].transpose(1, 2), h8["delta"].transpose(1, 2), h8["A"], h8["Bv"], h8["Cv"], h8["D"], h8["z"], None, False,
+                 out_z=y.transpose(1, 2), z_row_index=h8["perm"], out_row_index=h8["perm"], want_out=False, x=xc8, chunk_len=CH8, _probe_flags=flags)
+    return f
+
+
+# ---- B = 16 (320 workgroups = 1.25 waves per SIMD in one pass): would the sequence split pay here too?  (the split cannot carry dt_proj:
+# its cost is the dt_proj kernel + the two passes)
+from zigma_amd.selective_scan_interface import dt_proj_softplus
+xs16 = {c: torch.empty(16, Di, 1024 // c, 2 * N, device=dev, dtype=torch.float32) for c in (512, 256)}
+
+
+def scan_b16_split(name, ch):
+    def f():
+        use(NEW)
+        y = outs.setdefault(name, torch.empty(16, 1024, Di, device=dev, dtype=dt))
+        dl = dt_proj_softplus(h16["xdbl"], R, h16["w"], h16["db"], True)
+        scan_raw(h16["u"].transpose(1, 2), dl.transpose(1, 2), h16["A"], h16["Bv"], h16["Cv"], h16["D"], h16["z"], None, False,
+                 out_z=y.transpose(1, 2), z_row_index=h16["perm"], out_row_index=h16["perm"], want_out=False, x=xs16[ch], chunk_len=ch)
+    return f
+
+
 PR = 1 << _lib.SCAN_PROBE_PRIO_SHIFT
 groups = {
     "scan": {"r4": scan_dtp("s_r4", BASE), "r5": scan_dtp("s_r5", NEW), "r5_zact": scan_dtp("s_r5z", NEW, True)},
     "in_proj": {"r4": inproj(BASE), "r5": inproj(NEW), "r5_silu": inproj(NEW, True)},
-    "scan_b16": {"r4": scan_b16("b_r4", BASE), "r5": scan_b16("b_r5", NEW)},
+    "scan_b16": {"r4": scan_b16("b_r4", BASE), "r5": scan_b16("b_r5", NEW), "r5_dtproj_plus_split_512": scan_b16_split("b_s512", 512),
+                 "r5_dtproj_plus_split_256": scan_b16_split("b_s256", 256)},
+    "scan_b8_split": {"r4": scan_b8("e_r4", BASE), "r5_rot": scan_b8("e_r5", NEW), "r5_norot": scan_b8("e_r5n", NEW, PR)},
     "config4_split": {"r4": scan_c4("c_r4", BASE), "r5_rot": scan_c4("c_r5", NEW), "r5_norot": scan_c4("c_r5n", NEW, PR)},
 }
 res = {}
@@ -127,6 +161,7 @@ rel = lambda a, b: float((a.float() - b.float()).norm() / b.float().norm())
 res["scan"]["rel_diff_r5_vs_r4"] = rel(outs["s_r5"], outs["s_r4"])
 res["scan"]["rel_diff_zact_vs_r4"] = rel(outs["s_r5z"], outs["s_r4"])
 res["config4_split"]["rel_diff_r5_vs_r4"] = rel(outs["c_r5"], outs["c_r4"])
+res["scan_b8_split"]["chunk_len"] = CH8
 res["config4_split"]["rot_identical"] = bool(torch.equal(outs["c_r5"], outs["c_r5n"]))
 algo = 64 * 1024 * (4 * 2 * Di + 2 * 2 * N) + 4 * Di * (N + 2)
 res["scan"]["hbm_frac_formula"] = {k: round(algo / (v * 1e-6) / 8e12, 4) for k, v in res["scan"]["us_median"].items()}

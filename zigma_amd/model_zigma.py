@@ -126,8 +126,9 @@ class CrossAttention(nn.Module):
 
     @staticmethod
     def _proj(x, lin):
-        # to_q on the weight-stationary kernel where the 4-wave tiled kernel has too few tiles (< 32 768 tokens): 17.3 / 20.7 us at 8192 / 16 384
-        # tokens against 21.1 / 21.9 for the library and 20.8 / 22.7 for the 8-wave kernel (profiles/r05_b_shapes_probe.jsonl); above, a tie (r4)
+        # to_q on the weight-stationary kernel at 8192 tokens: 17.3 us against 21.1 for the library and 20.8 for the 8-wave kernel stand-alone
+        # (profiles/r05_b_shapes_probe.jsonl), 5.6-5.9 against 6.0 ms per B = 8 forward; at 16 384 tokens stand-alone 20.7 against 21.9 but the
+        # forward LOSES 3 % with it (7.49 against 7.27 ms, profiles/r05_d_small_batch_ab.jsonl), and from 32 768 on it ties the 4-wave kernel (r4)
         if (lin.bias is None and not (torch.is_grad_enabled() and (x.requires_grad or lin.weight.requires_grad))
                 and (TO_Q_WS or x.shape[:-1].numel() <= TO_Q_WS_MAX_TOKENS) and linear_ws_eligible(x, lin.weight)):
             return linear(x, lin.weight, weight_stationary=True)
@@ -282,7 +283,7 @@ class Pending:
 # pre-attention add + norm 68 -> 47, and with to_out's gated add: to_out 63 -> 78, pre-mixer add + norm 119 -> 102 — time moves from
 # the HBM-bound norm kernels into the projection epilogues, the forward is 0.1-0.3 % faster.
 TEXT_PROJ_OWN = os.environ.get("ZIGMA_TEXT_PROJ_OWN", "1") == "1"
-TO_Q_WS_MAX_TOKENS = int(os.environ.get("ZIGMA_TO_Q_WS_MAX_TOKENS", "16384"))
+TO_Q_WS_MAX_TOKENS = int(os.environ.get("ZIGMA_TO_Q_WS_MAX_TOKENS", "8192"))
 TO_Q_WS = os.environ.get("ZIGMA_TO_Q_WS", "0") == "1"      # to_q on the weight-stationary kernel (A/B knob: a tie stand-alone)   # y_embedder and the batched K / V projection of all blocks (B x 77 text rows) on zigma_linear_fwd, rows padded to 256
 
 
