@@ -54,11 +54,17 @@ WORKLOADS = {
 
 
 class ScanTimer:
-    """HIP-event pairs around every scan launch (events are recorded on the stream the kernel goes to)."""
+    """HIP-event pairs around scan launches (events are recorded on the stream the kernel goes to).  `every` = bracket every n-th launch:
+    an event pair costs the stream ~6 us of idle time on either side of the kernel it brackets (kernel trace of round 5,
+    profiles/r05_e_bench_kernel_trace_gaps.txt: 5.7 + 6.0 us around every scan against 0 between all other kernels), i.e. 216 us = 1.2 % of
+    the forward with all 18 launches bracketed.  The default 7 is coprime with the 18 launches of a forward: over the timed steps every layer
+    is sampled (51 pairs in 20 steps), the step carries 2-3 pairs instead of 18."""
 
-    def __init__(self):
+    def __init__(self, every=1):
         self.pairs = []
         self.enabled = False
+        self.every = max(1, int(every))
+        self.count = 0
 
     def install(self):
         from zigma_amd import selective_scan_interface as ssi
@@ -67,6 +73,9 @@ class ScanTimer:
 
         def timed(*a, **k):
             if not timer.enabled:
+                return raw(*a, **k)
+            timer.count += 1
+            if timer.count % timer.every:
                 return raw(*a, **k)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
@@ -365,6 +374,7 @@ def main():
     ap.add_argument("--batch", type=int, default=None, help="per-GPU batch (default: the workload's)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-scan-events", action="store_true")
+    ap.add_argument("--scan-events-every", type=int, default=7, help="bracket every n-th scan launch of the timed region with HIP events (1: all)")
     ap.add_argument("--no-check", action="store_true",
                     help="skip the untimed self-check forward (kernel traces of the timed path: its unfused composition runs library GEMMs)")
     ap.add_argument("--cpu-baseline-only", default=None, help=argparse.SUPPRESS)      # child-process leg of cpu_baseline()
@@ -396,7 +406,7 @@ def main():
     L = (wl["model"]["img_dim"] // wl["model"]["patch_size"]) ** 2
     gathered = torch.empty((world * batch,) + wl["x"], device=device) if world > 1 else None
 
-    timer = ScanTimer()
+    timer = ScanTimer(every=args.scan_events_every)
     timer.install()
 
     def step():
@@ -440,7 +450,7 @@ def main():
             valu_floor_measured_us = groups / 4 * (4 * 3.43 + 6 * 2.28 + 4 * 1.35) * 1e-9 / 1024 * 1e6
             roof = dict(bound="hbm", kernel="scan_tok2 (fused zigzag selective scan" + (", dt_proj + softplus inside" if dt_in else "") + ")", achieved=ach / 1e9,
                         peak=HBM_PEAK / 1e9, unit="GB/s", frac=ach / HBM_PEAK, traffic=traffic,
-                        traffic_source=traffic_src, launch_us=ms * 1e3, launches=len(timer.pairs),
+                        traffic_source=traffic_src, launch_us=ms * 1e3, launches=len(timer.pairs), launches_bracketed="every %d-th of %d" % (timer.every, timer.count),
                         algorithmic_bytes=algo_bytes, algorithmic_bytes_note="SURVEY 8(d) formula of the selective scan (u, delta, z, out_z, B, C)",
                         bytes_moved_by_design=moved_bytes, frac_of_bytes_moved=moved_bytes / (ms * 1e-3) / HBM_PEAK,
                         dt_proj_inside=bool(dt_in), limiter="valu", valu_floor_us=valu_floor_us,
