@@ -127,7 +127,7 @@ typedef struct zigma_scan_params {
      * already fetches B_l / C_l from — the (batch, seqlen, dim) delta tensor (reference selective_scan_interface.py:323) is
      * neither written nor read.  dt_x: rows of scan position l (row pitch dt_x_l_stride, 16-byte aligned), dt_w: (dim, dt_rank)
      * rows of pitch dt_w_row_stride (16-byte aligned); 32 <= dt_rank <= 64, dt_rank % 8 == 0, dt_x rows at least 64 wide.
-     * delta_softplus must be 1. */
+     * delta_softplus must be 1.  ZIGMA_SCAN_Z_PREACTIVATED may be combined with it (round 5). */
     const void *dt_x, *dt_w;
     int64_t dt_x_batch_stride, dt_x_l_stride, dt_w_row_stride;
     int32_t dt_rank, pad3_;
@@ -438,7 +438,8 @@ int zigma_cross_attn_bwd(const zigma_xattn_bwd_params_t *p, void *stream);
  * x_proj: out[m, n] = sum_k x[m, k] * w[n, k]  for the skinny projection of the Mamba block (n = dt_rank + 2 d_state).
  * Replaces F.linear(conv1d_out, x_proj_weight) (reference dis_mamba/mamba_ssm/ops/selective_scan_interface.py:318-322).
  * x: (m, k) rows (the conv output u, token-major); w: (n, k) = x_proj.weight; out: (m, n).  bf16 in, fp32 accumulate,
- * bf16 out.  Limits: n <= 96, k % 256 == 0, x / w rows 16-byte aligned.
+ * bf16 out.  Limits: n <= 96, k % 256 == 0, x / w rows 16-byte aligned.  Below 16 384 rows (and k <= 1536) the library splits K over the
+ * waves of 32-row workgroups and adds the partial tiles in a fixed order (round 5); from 16 384 rows on a workgroup streams 256 rows.
  * ------------------------------------------------------------------------------------------ */
 typedef struct zigma_xproj_params {
     int64_t m;
@@ -487,10 +488,12 @@ int zigma_conv_x_proj_fwd(const zigma_conv_xproj_params_t *p, void *stream);
  * silu_from_col: output columns >= this value leave as silu(value) (in_proj writes silu(z) for the gate half, consumed by
  * the scan under ZIGMA_SCAN_Z_PREACTIVATED); pass n for a plain projection.  Must be a multiple of 32.
  * Limits: bf16; k % 64 == 0; n % 128 == 0; x / w rows 16-byte aligned, out rows 8-byte aligned.
- * ZIGMA_LINEAR_WS (flags): the weight-stationary kernel (csrc/linear_ws.hip — a 256-feature panel of w lives in the registers of a
- * workgroup, only the rows of x stream; the in_proj of the default path).  Same result bit for bit.  Limits, else ZIGMA_ERR_UNSUPPORTED:
- * no bias / activation / residual, k = 512 or 640, n % 256 == 0 and n <= 8192, m % 512 == 0 with m / 512 >= 32 / (n / 256),
- * x rows a multiple of 128 elements apart, out rows 16-byte aligned.
+ * ZIGMA_LINEAR_WS (flags): the weight-stationary kernel (csrc/linear_ws.hip — a panel of w lives in the registers of a workgroup, only
+ * the rows of x stream; the in_proj of the default path).  Same result bit for bit.  Limits, else ZIGMA_ERR_UNSUPPORTED: no bias /
+ * residual; k = 512 or 640 with 256-feature panels (pw = 256), or — since round 5 — k = 1280 or 1536 with 128-feature panels (pw = 128:
+ * out_proj below the tiled kernel's token floor); n % pw == 0 and n <= 8192, m % 512 == 0 with m / 512 >= 32 / (n / pw), x rows a
+ * multiple of 128 elements apart, out rows 16-byte aligned.  silu_from_col < n (round 5, pw = 256 only): a multiple of 128 — whole
+ * 128-column groups leave as silu(.) of the fp32 accumulator.
  * ------------------------------------------------------------------------------------------ */
 #define ZIGMA_LINEAR_WS 0x4000
 typedef struct zigma_linear_params {

@@ -168,8 +168,10 @@ def test_bench_block_path_vs_reference(variant, monkeypatch):
             import zigma_amd.mamba_simple as zms
             n_ws128 = counts.get(("zigma_linear_fwd", "linear_ws_128"), 0)
             want128 = depth if zms.OUT_PROJ_WS_MAX_TOKENS > Bsz * 1024 else 0
-            n_toq_ws = depth if mz.TO_Q_WS_MAX_TOKENS >= Bsz * 1024 else 0       # (8192: to_q stays the library's at 16 384 tokens, the forward is faster so)
-            assert n_ws == depth + n_toq_ws and n_ws128 == want128 and n_lin == 2 * depth + n_toq_ws + want128 + 2, (n_ws, n_ws128, n_lin, counts)
+            n_toq_ws = depth if mz.TO_Q_WS_MAX_TOKENS >= Bsz * 1024 else 0       # (8192: at 16 384 tokens to_q runs on the 8-wave tiled kernel)
+            n_toq_own = depth if (n_toq_ws or mz.TO_Q_OWN_MIN_TOKENS <= Bsz * 1024) else 0
+            assert n_ws == depth + n_toq_ws and n_ws128 == want128 and n_lin == 2 * depth + n_toq_own + want128 + 2, (n_ws, n_ws128, n_lin, counts)
+            assert not any(k.startswith("Cijk") for (_, k), _ in counts.items())
     elif variant == "unfused_out_proj":
         assert gated == depth, (gated, counts)              # to_out only
     elif variant == "linear_all":

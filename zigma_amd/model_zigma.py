@@ -134,6 +134,11 @@ class CrossAttention(nn.Module):
             return linear(x, lin.weight, weight_stationary=True)
         if linear_eligible(x, lin.weight, lin.bias):
             return linear(x, lin.weight, lin.bias)
+        # between the two (16 384 tokens: too few tiles for the 4-wave kernel, and the weight-stationary kernel slows the forward there): the
+        # 8-wave tiled kernel, 22.7-23.7 us against 20.9-21.9 for the library stand-alone — taken so that no library GEMM is left in the block
+        # loop at serving-size batches either (B = 16: 7.17 ms per forward with it against 7.16-7.35 at the end of round 4)
+        if (lin.bias is None and x.shape[:-1].numel() >= TO_Q_OWN_MIN_TOKENS and linear_eligible(x, lin.weight, None, prefer_own=True)):
+            return linear(x, lin.weight)
         return linear_train(x, lin.weight, lin.bias)       # (F.linear; under autograd with the slab-wise weight gradient, zigma_amd/wgrad.py)
 
     def _proj_out(self, o, residual, gate):
@@ -284,6 +289,7 @@ class Pending:
 # the HBM-bound norm kernels into the projection epilogues, the forward is 0.1-0.3 % faster.
 TEXT_PROJ_OWN = os.environ.get("ZIGMA_TEXT_PROJ_OWN", "1") == "1"
 TO_Q_WS_MAX_TOKENS = int(os.environ.get("ZIGMA_TO_Q_WS_MAX_TOKENS", "8192"))
+TO_Q_OWN_MIN_TOKENS = int(os.environ.get("ZIGMA_TO_Q_OWN_MIN_TOKENS", "8192"))
 TO_Q_WS = os.environ.get("ZIGMA_TO_Q_WS", "0") == "1"      # to_q on the weight-stationary kernel (A/B knob: a tie stand-alone)   # y_embedder and the batched K / V projection of all blocks (B x 77 text rows) on zigma_linear_fwd, rows padded to 256
 
 
