@@ -41,6 +41,7 @@ extern "C" {
 #define ZIGMA_SCAN_Z_PREACTIVATED 2   /* z already holds silu(z) (the in_proj GEMM epilogue applied it): out_z = y * z */
 #define ZIGMA_SCAN_PROBE_V1 0x100     /* A/B probe (tools/scan_ab.py): pin the first-generation token-major kernel */
 #define ZIGMA_SCAN_PROBE_PRIO_SHIFT 9 /* A/B probe: bit 9 = scan_tok2_kernel WITHOUT its wave-priority rotation */
+#define ZIGMA_SCAN_PROBE_R5_SHIFT 10  /* A/B probe: bit 10 = never the six-resident-workgroups form of scan_tok2_kernel */
 
 /* zigma_scan_params_t.info[0]: which kernel family served the call */
 #define ZIGMA_SCAN_KERNEL_GENERIC 1

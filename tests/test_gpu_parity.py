@@ -439,7 +439,7 @@ def test_dt_proj_softplus_mfma_vs_oracle(M, Di, R, S):
 
 
 @pytest.mark.parametrize("Bsz,L,Di,R,use_perm", [(2, 64, 128, 40, False), (3, 1024, 192, 40, True), (2, 256, 64, 48, True),
-                                                 (5, 48, 1280, 40, True), (1, 16, 64, 32, False)])
+                                                 (5, 48, 1280, 40, True), (1, 16, 64, 32, False), (64, 32, 1536, 48, True), (22, 48, 4096, 40, False)])
 @pytest.mark.parametrize("io", ["bf16", "f16"])
 def test_scan_tok2_dt_proj_in_kernel_vs_oracle(Bsz, L, Di, R, use_perm, io):
     """ABI 9: dt_proj + bias + softplus inside scan_tok2_kernel (zigma_scan_params_t.dt_x / dt_w) against the numpy oracle's scan on
@@ -469,7 +469,14 @@ def test_scan_tok2_dt_proj_in_kernel_vs_oracle(Bsz, L, Di, R, use_perm, io):
     info = []
     scan_raw(ut.transpose(1, 2), None, T(A), Bv, Cv, T(D), zt.transpose(1, 2), T(db), True, out_z=y.transpose(1, 2),
              z_row_index=pt, out_row_index=pt, want_out=False, dt_x=xt, dt_w=wt, info=info)
-    assert _lib.last_kernel() == "scan_tok2_n16_dtproj" and info[0] == _lib.SCAN_KERNEL_TOK2
+    # (1536 / 1408 workgroups: one round of SIX resident workgroups per CU instead of a round of five and a tail — the R6 form, round 5)
+    r6 = -(-Bsz * (Di // 64) // 1536) < -(-Bsz * (Di // 64) // 1280)
+    assert _lib.last_kernel() == ("scan_tok2_n16_dtproj_r6" if r6 else "scan_tok2_n16_dtproj") and info[0] == _lib.SCAN_KERNEL_TOK2
+    if r6:      # the five-resident form pinned by the probe bit: same arithmetic, operands fetched one step earlier -> bit-identical
+        y5 = torch.empty_like(y)
+        scan_raw(ut.transpose(1, 2), None, T(A), Bv, Cv, T(D), zt.transpose(1, 2), T(db), True, out_z=y5.transpose(1, 2),
+                 z_row_index=pt, out_row_index=pt, want_out=False, dt_x=xt, dt_w=wt, _probe_flags=1 << _lib.SCAN_PROBE_R5_SHIFT)
+        assert _lib.last_kernel() == "scan_tok2_n16_dtproj" and torch.equal(y5, y)
     # oracle: scan position k reads z from row perm[k] and writes row perm[k]
     delta = np.einsum("blr,dr->bdl", xd[:, :, :R].astype(np.float32), w.astype(np.float32))
     zz = z if perm is None else z[:, perm]

@@ -133,12 +133,32 @@ def scan_b16_split(name, ch):
     return f
 
 
+# ---- the E = 768 models (Di = 1536, R = 48) at B = 64: 1536 workgroups = one round of six per CU (R6 form) vs a round of five + a tail
+Di7, R7 = 1536, 48
+torch.manual_seed(1)
+g7 = dict(xz=torch.randn(64, 1024, 2 * Di7, device=dev, dtype=dt), u=torch.randn(64, 1024, Di7, device=dev, dtype=dt),
+          xdbl=torch.randn(64, 1024, R7 + 2 * N, device=dev, dtype=dt), w=(R7 ** -0.5 * torch.randn(Di7, R7, device=dev)).to(dt), db=torch.randn(Di7, device=dev) - 3,
+          A=-torch.exp(torch.log(torch.arange(1, N + 1, device=dev).float()) + 0.1 * torch.randn(Di7, N, device=dev)).contiguous(), D=torch.randn(Di7, device=dev),
+          perm=torch.randperm(1024, device=dev).to(torch.int32))
+
+
+def scan_e768(name, lib, flags=0):
+    def f():
+        use(lib)
+        y = outs.setdefault(name, torch.empty(64, 1024, Di7, device=dev, dtype=dt))
+        scan_raw(g7["u"].transpose(1, 2), None, g7["A"], g7["xdbl"][:, :, R7:R7 + N].transpose(1, 2).unsqueeze(1), g7["xdbl"][:, :, R7 + N:].transpose(1, 2).unsqueeze(1),
+                 g7["D"], g7["xz"][:, :, Di7:].transpose(1, 2), g7["db"], True, out_z=y.transpose(1, 2), z_row_index=g7["perm"], out_row_index=g7["perm"],
+                 want_out=False, dt_x=g7["xdbl"], dt_w=g7["w"], _probe_flags=flags)
+    return f
+
+
 PR = 1 << _lib.SCAN_PROBE_PRIO_SHIFT
 groups = {
     "scan": {"r4": scan_dtp("s_r4", BASE), "r5": scan_dtp("s_r5", NEW), "r5_zact": scan_dtp("s_r5z", NEW, True)},
     "in_proj": {"r4": inproj(BASE), "r5": inproj(NEW), "r5_silu": inproj(NEW, True)},
     "scan_b16": {"r4": scan_b16("b_r4", BASE), "r5": scan_b16("b_r5", NEW), "r5_dtproj_plus_split_512": scan_b16_split("b_s512", 512),
                  "r5_dtproj_plus_split_256": scan_b16_split("b_s256", 256)},
+    "scan_e768_b64": {"r4": scan_e768("g_r4", BASE), "r5_six_resident": scan_e768("g_r5", NEW), "r5_five_resident": scan_e768("g_r55", NEW, 1 << 10)},
     "scan_b8_split": {"r4": scan_b8("e_r4", BASE), "r5_rot": scan_b8("e_r5", NEW), "r5_norot": scan_b8("e_r5n", NEW, PR)},
     "config4_split": {"r4": scan_c4("c_r4", BASE), "r5_rot": scan_c4("c_r5", NEW), "r5_norot": scan_c4("c_r5n", NEW, PR)},
 }
@@ -162,6 +182,7 @@ res["scan"]["rel_diff_r5_vs_r4"] = rel(outs["s_r5"], outs["s_r4"])
 res["scan"]["rel_diff_zact_vs_r4"] = rel(outs["s_r5z"], outs["s_r4"])
 res["config4_split"]["rel_diff_r5_vs_r4"] = rel(outs["c_r5"], outs["c_r4"])
 res["scan_b8_split"]["chunk_len"] = CH8
+res["scan_e768_b64"]["six_vs_five_identical"] = bool(torch.equal(outs["g_r5"], outs["g_r55"]))
 res["config4_split"]["rot_identical"] = bool(torch.equal(outs["c_r5"], outs["c_r5n"]))
 algo = 64 * 1024 * (4 * 2 * Di + 2 * 2 * N) + 4 * Di * (N + 2)
 res["scan"]["hbm_frac_formula"] = {k: round(algo / (v * 1e-6) / 8e12, 4) for k, v in res["scan"]["us_median"].items()}

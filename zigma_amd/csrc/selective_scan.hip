@@ -189,7 +189,7 @@ extern "C" int zigma_selective_scan_fwd(const zigma_scan_params_t *pp, void *str
 #else
     constexpr int kProbeBits = 0;
 #endif
-    if (p.flags & ~(ZIGMA_SCAN_Z_PREACTIVATED | ZIGMA_SCAN_PROBE_V1 | (1 << ZIGMA_SCAN_PROBE_PRIO_SHIFT) | kProbeBits)) return ZIGMA_ERR_UNSUPPORTED;
+    if (p.flags & ~(ZIGMA_SCAN_Z_PREACTIVATED | ZIGMA_SCAN_PROBE_V1 | (1 << ZIGMA_SCAN_PROBE_PRIO_SHIFT) | (1 << ZIGMA_SCAN_PROBE_R5_SHIFT) | kProbeBits)) return ZIGMA_ERR_UNSUPPORTED;
     if (p.batch == 0 || p.dim == 0 || p.seqlen == 0) return ZIGMA_OK;  // empty (pointers may be NULL): nothing to launch
     if (p.dt_x) {       // ABI 9: dt_proj inside the token-major hot kernel; `delta` is not read (the layout checks below see u's strides)
         if (!p.u || !p.dt_w || !p.A || !p.B || !p.C || !p.z || !p.out_z) return ZIGMA_ERR_NULL;
