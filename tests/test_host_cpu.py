@@ -82,6 +82,22 @@ def test_flag_constants_match_the_header():
     assert defs["ZIGMA_ABI_VERSION"] == 9
 
 
+def test_knobs_env_override():
+    """ZIGMA_KNOBS: the one environment override of the module-level routing constants (A/B tools); unknown names raise"""
+    import subprocess
+    import sys
+    code = ("import zigma_amd.mamba_simple as m, zigma_amd.model_zigma as z, zigma_amd.linear as l; "
+            "print(m.GATE_IN_IN_PROJ, m.OUT_PROJ_WS_MAX_TOKENS, z.TO_Q_WS_MAX_TOKENS, l.AUTO_4W_MAX_N)")
+    env = dict(os.environ, ZIGMA_KNOBS="mamba_simple.GATE_IN_IN_PROJ=True, mamba_simple.OUT_PROJ_WS_MAX_TOKENS=0,model_zigma.TO_Q_WS_MAX_TOKENS=16384,linear.AUTO_4W_MAX_N=512")
+    out = subprocess.run([sys.executable, "-c", code], cwd=ROOT, env=env, capture_output=True, text=True)
+    assert out.returncode == 0 and out.stdout.split() == ["True", "0", "16384", "512"], (out.stdout, out.stderr[-400:])
+    out = subprocess.run([sys.executable, "-c", code], cwd=ROOT, env=dict(os.environ, ZIGMA_KNOBS=""), capture_output=True, text=True)
+    assert out.stdout.split() == ["False", "32768", "8192", "1024"], out.stdout
+    bad = subprocess.run([sys.executable, "-c", "import zigma_amd.mamba_simple"], cwd=ROOT, env=dict(os.environ, ZIGMA_KNOBS="mamba_simple.NO_SUCH=1"),
+                         capture_output=True, text=True)
+    assert bad.returncode != 0 and "no knob" in bad.stderr
+
+
 def test_linear_ws_policy_limits_on_cpu_tensors():
     """linear_ws_eligible never claims a CPU tensor or a shape outside the kernel's limits (the C side re-checks and refuses)"""
     from zigma_amd.linear import linear_ws_eligible

@@ -17,7 +17,7 @@ rm -f gpurun_out/r05_c1_fwd_ab.jsonl
 for rep in 1 2; do
   fwd r4_lib ZIGMA_AMD_LIB=$R/tools/libzigma_base_r04.so
   fwd r5 X=1
-  fwd r5_gate_in_in_proj ZIGMA_GATE_IN_IN_PROJ=1
+  fwd r5_gate_in_in_proj ZIGMA_KNOBS=mamba_simple.GATE_IN_IN_PROJ=True
 done
 python -m pytest tests -x -q -m gpu 2>&1 | tail -8 > gpurun_out/r05_c1_gpu_tests_tail.txt
 cat gpurun_out/r05_c1_gpu_tests_tail.txt

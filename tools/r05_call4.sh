@@ -16,10 +16,10 @@ print(json.dumps(dict(label='$label', batch=$b, ms_per_step=d['ms_per_step'], sc
 }
 rm -f gpurun_out/r05_c4_small_batch_ab.jsonl
 for rep in 1 2; do for b in 8 16; do
-  fwd r4_lib_r4_policy $b ZIGMA_AMD_LIB=$R/tools/libzigma_base_r04.so ZIGMA_OUT_PROJ_FUSE_NEEDS_4W=0 ZIGMA_TO_Q_WS_MAX_TOKENS=0 ZIGMA_OUT_PROJ_WS_MAX_TOKENS=0
-  fwd r5_lib_r4_policy $b ZIGMA_OUT_PROJ_FUSE_NEEDS_4W=0 ZIGMA_TO_Q_WS_MAX_TOKENS=0 ZIGMA_OUT_PROJ_WS_MAX_TOKENS=0
-  fwd r5_out_proj_library $b ZIGMA_OUT_PROJ_WS_MAX_TOKENS=0
-  fwd r5_no_toq_ws $b ZIGMA_TO_Q_WS_MAX_TOKENS=0
+  fwd r4_lib_r4_policy $b ZIGMA_AMD_LIB=$R/tools/libzigma_base_r04.so ZIGMA_KNOBS=mamba_simple.OUT_PROJ_FUSE_NEEDS_4W=False,model_zigma.TO_Q_WS_MAX_TOKENS=0,model_zigma.TO_Q_OWN_MIN_TOKENS=1000000000,mamba_simple.OUT_PROJ_WS_MAX_TOKENS=0
+  fwd r5_lib_r4_policy $b ZIGMA_KNOBS=mamba_simple.OUT_PROJ_FUSE_NEEDS_4W=False,model_zigma.TO_Q_WS_MAX_TOKENS=0,model_zigma.TO_Q_OWN_MIN_TOKENS=1000000000,mamba_simple.OUT_PROJ_WS_MAX_TOKENS=0
+  fwd r5_out_proj_library $b ZIGMA_KNOBS=mamba_simple.OUT_PROJ_WS_MAX_TOKENS=0
+  fwd r5_no_toq_ws $b ZIGMA_KNOBS=model_zigma.TO_Q_WS_MAX_TOKENS=0
   fwd r5 $b X=1
 done; done
 python -m pytest tests -x -q -m gpu 2>&1 | tail -8 > gpurun_out/r05_c4_gpu_tests_tail.txt

@@ -29,6 +29,10 @@ FORCE_8W = os.environ.get("ZIGMA_LINEAR_8W", "0") == "1"      # A/B knob of tool
 AUTO_4W_MAX_N = int(os.environ.get("ZIGMA_4W_MAX_N", "1024"))   # "auto": the 4-wave kernel where it at least ties the library (to_q; not in_proj)
 
 
+from . import _knobs  # noqa: E402
+_knobs.apply(globals(), "linear")
+
+
 def linear_eligible(x, weight, bias=None, fused_epilogue=False, prefer_own=False):
     """policy (LINEAR_POLICY) + limits of zigma_linear_fwd: bf16, k % 64 == 0, n % 128 == 0, tokens % 8 == 0, aligned contiguous
     rows, no autograd"""

@@ -15,6 +15,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from . import _knobs
 from . import linear as _zl
 from .linear import gated_residual_eligible, linear, linear_eligible, linear_ws_eligible, routes_to_4w
 from .selective_scan_interface import mamba_inner_tok
@@ -30,14 +31,15 @@ IN_PROJ_WS = os.environ.get("ZIGMA_IN_PROJ_WS", "1") == "1"            # in_proj
 # (tools/linear_ws_probe.py with M=...)
 IN_PROJ_WS_MIN_TOKENS = 8192
 # in_proj of the wider models (k >= this: E = 768 of the reference's shipped yamls, config/model/zigzag8_b1_pe2.yaml:7-8) as ONE launch of the tiled kernel; 0: off
-IN_PROJ_ONE_LAUNCH_K = int(os.environ.get("ZIGMA_IN_PROJ_ONE_LAUNCH_K", "704"))
+IN_PROJ_ONE_LAUNCH_K = 704
 # the SiLU of the gate in in_proj's epilogue (linear_ws_kernel<.., SL>: z leaves as silu(z)) instead of in the scan's (ZIGMA_SCAN_Z_PREACTIVATED):
 # 20 of the scan's 311 VALU instructions per tile-wave move into the GEMM's MFMA gaps; the gate is then rounded to bf16 once more than in the
 # reference (selective_scan_fwd_kernel.cuh:293 applies silu in fp32 to the bf16 z).  Measured in round 5: see there for the default.
 # out_proj (k = 1280 / 1536) on the weight-stationary kernel's 128-feature-panel form below the tiled 4-wave kernel's token floor (round 5)
-OUT_PROJ_WS_MAX_TOKENS = int(os.environ.get("ZIGMA_OUT_PROJ_WS_MAX_TOKENS", "32768"))
-OUT_PROJ_FUSE_NEEDS_4W = os.environ.get("ZIGMA_OUT_PROJ_FUSE_NEEDS_4W", "1") == "1"
-GATE_IN_IN_PROJ = os.environ.get("ZIGMA_GATE_IN_IN_PROJ", "0") == "1"
+OUT_PROJ_WS_MAX_TOKENS = 32768
+OUT_PROJ_FUSE_NEEDS_4W = True
+GATE_IN_IN_PROJ = False
+_knobs.apply(globals(), "mamba_simple")      # ZIGMA_KNOBS="mamba_simple.GATE_IN_IN_PROJ=True,..." (A/B tools)
 
 
 def _int32_table(t, device):

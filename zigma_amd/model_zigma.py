@@ -288,8 +288,8 @@ class Pending:
 # pre-attention add + norm 68 -> 47, and with to_out's gated add: to_out 63 -> 78, pre-mixer add + norm 119 -> 102 — time moves from
 # the HBM-bound norm kernels into the projection epilogues, the forward is 0.1-0.3 % faster.
 TEXT_PROJ_OWN = os.environ.get("ZIGMA_TEXT_PROJ_OWN", "1") == "1"
-TO_Q_WS_MAX_TOKENS = int(os.environ.get("ZIGMA_TO_Q_WS_MAX_TOKENS", "8192"))
-TO_Q_OWN_MIN_TOKENS = int(os.environ.get("ZIGMA_TO_Q_OWN_MIN_TOKENS", "8192"))
+TO_Q_WS_MAX_TOKENS = 8192
+TO_Q_OWN_MIN_TOKENS = 8192
 TO_Q_WS = os.environ.get("ZIGMA_TO_Q_WS", "0") == "1"      # to_q on the weight-stationary kernel (A/B knob: a tie stand-alone)   # y_embedder and the batched K / V projection of all blocks (B x 77 text rows) on zigma_linear_fwd, rows padded to 256
 
 
@@ -312,6 +312,8 @@ def _padded_own_linear(x, weight, bias):
 
 FUSE_OUT_PROJ_ADD = True       # (module-level knob for tests / tools; no environment switch)
 FUSE_OUT_PROJ_ADD_NO_TEXT = True     # the same for blocks without the attention branch (tools/outproj_notext_ab.py: 14.82 -> 14.78 ms on config 3's model)
+from . import _knobs  # noqa: E402
+_knobs.apply(globals(), "model_zigma")      # ZIGMA_KNOBS="model_zigma.TO_Q_WS_MAX_TOKENS=0,..." (A/B tools)
 
 
 class Block(nn.Module):

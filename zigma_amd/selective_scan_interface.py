@@ -254,6 +254,10 @@ def conv_x_proj(x_half, conv_w, conv_b, x_proj_weight, perm=None, _flags=0):
 DT_PROJ_IN_SCAN = os.environ.get("ZIGMA_DT_IN_SCAN", "1") == "1"     # dt_proj + softplus in the scan's tile prologue (MFMA) instead of a kernel of its own
 
 
+from . import _knobs  # noqa: E402
+_knobs.apply(globals(), "selective_scan_interface")      # (SPLIT_MAX_WGS, CONV_X_PROJ_MIN_POSITIONS, ... for the A/B tools)
+
+
 def dt_in_scan_eligible(u, x_dbl, weight, reset_period=0, out=None, dstate=16, z=None):
     """limits of the in-kernel dt_proj of scan_tok2_kernel (zigma_scan_params_t.dt_x), mirroring tok2_dtp_ok() / tok2_layout_ok() /
     tok_eligible() of csrc/: bf16 / fp16, whole-sequence mode of the hot kernel (dstate == 16, seqlen % 16 == 0, d_inner % 64 == 0, no
