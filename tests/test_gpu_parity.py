@@ -1107,6 +1107,38 @@ def test_linear_ws_silu_epilogue(M, K, N, col):
         linear(x, w, weight_stationary=True, silu_from_col=col + 64)
 
 
+@pytest.mark.parametrize("M,K,N", [(8192, 1280, 640), (16384, 1536, 768), (128, 128, 640), (384, 192, 768), (8192, 512, 640), (2048, 1280, 1920), (4096 + 128, 640, 1280)])
+def test_linear_sm_kernel(M, K, N):
+    """The few-token tiled projection kernel (csrc/linear_sm.hip, round 5: out_proj below the 4-wave kernel's token floor): sampled rows against
+    float64 on the same bf16 operands; the WHOLE result bit-identical with the 8-wave tiled kernel (same MFMA, same accumulation order over k:
+    covers every tile and wave boundary); run-to-run identity; a strided output; the limits."""
+    from zigma_amd import _lib
+    from zigma_amd.linear import linear, linear_sm_eligible
+    g = torch.Generator(device="cpu").manual_seed(M + N + K + 7)
+    x = torch.randn(M, K, generator=g).to(DEV, torch.bfloat16)
+    w = (torch.randn(N, K, generator=g) * K ** -0.5).to(DEV, torch.bfloat16)
+    assert linear_sm_eligible(x, w)
+    y = linear(x, w, few_tokens=True)
+    assert _lib.last_kernel() == ("linear_sm_128x160" if N % 160 == 0 else "linear_sm_128x192") and y.shape == (M, N)
+    rows = torch.randint(0, M, (min(M, 1024),), generator=g).to(DEV)
+    rows[:4] = torch.tensor([0, 31, 127, M - 1], device=DEV)
+    ref = x[rows].double() @ w.double().T
+    got = y[rows].double()
+    assert float((got - ref).norm() / ref.norm()) < 2.5e-3
+    assert torch.allclose(got, ref, rtol=1.6e-2, atol=1e-2)
+    y8 = linear(x, w, _probe_flags=0x2000)
+    assert _lib.last_kernel().startswith("linear_tn_")
+    assert torch.equal(y, y8)
+    for _ in range(3):
+        assert torch.equal(linear(x, w, few_tokens=True), y)
+    wide = torch.zeros(M, N + 256, device=DEV, dtype=torch.bfloat16)
+    linear(x, w, out=wide[:, 128:128 + N], few_tokens=True)
+    assert torch.equal(wide[:, 128:128 + N], y) and float(wide[:, :128].abs().max()) == 0 and float(wide[:, 128 + N:].abs().max()) == 0
+    assert not linear_sm_eligible(x[:104], w) and not linear_sm_eligible(x, w[:128])
+    with pytest.raises(RuntimeError):
+        linear(x, w[:128], few_tokens=True)
+
+
 def test_linear_ws_limits():
     from zigma_amd.linear import linear, linear_ws_eligible
     x = torch.randn(4096, 640, device=DEV).bfloat16()

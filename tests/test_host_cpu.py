@@ -75,7 +75,7 @@ def test_flag_constants_match_the_header():
     import zigma_amd.linear as zl
     hdr = open(os.path.join(ROOT, "include", "zigma_hip.h")).read()
     defs = {m.group(1): int(m.group(2), 0) for m in re.finditer(r"#define\s+(ZIGMA_\w+)\s+(0x[0-9a-fA-F]+|\d+)\b", hdr)}
-    assert defs["ZIGMA_LINEAR_WS"] == zl.LINEAR_WS_FLAG
+    assert defs["ZIGMA_LINEAR_WS"] == zl.LINEAR_WS_FLAG and defs["ZIGMA_LINEAR_SM"] == zl.LINEAR_SM_FLAG
     assert defs["ZIGMA_SCAN_KERNEL_TOK2"] == _lib.SCAN_KERNEL_TOK2
     assert defs["ZIGMA_SCAN_Z_PREACTIVATED"] == _lib.SCAN_Z_PREACTIVATED and defs["ZIGMA_SCAN_PROBE_V1"] == _lib.SCAN_PROBE_V1
     assert defs["ZIGMA_SCAN_PROBE_PRIO_SHIFT"] == _lib.SCAN_PROBE_PRIO_SHIFT and defs["ZIGMA_SCAN_PROBE_R5_SHIFT"] == _lib.SCAN_PROBE_R5_SHIFT

@@ -8,7 +8,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from zigma_amd import _lib
 import zigma_amd.linear as zl
-from zigma_amd.linear import linear, linear_eligible, linear_ws_eligible
+from zigma_amd.linear import linear, linear_eligible, linear_sm_eligible, linear_ws_eligible
 from zigma_amd.selective_scan_interface import x_proj
 F = torch.nn.functional
 dev, dt = "cuda", torch.bfloat16
@@ -56,6 +56,8 @@ for name, M, K, N in shapes:
             halves(); kern["own_halves"] = _lib.last_kernel()
     if linear_ws_eligible(x, w):
         fs["own_ws"] = lambda: linear(x, w, weight_stationary=True)
+    if linear_sm_eligible(x, w):
+        fs["own_sm"] = lambda: linear(x, w, few_tokens=True)
     ref = F.linear(x, w)
     errs = {k: float((f() if k not in ("own_halves",) else (f(), o)[1]).float().sub(ref.float()).norm() / ref.float().norm()) for k, f in fs.items() if k != "lib"}
     us = timeit(fs)

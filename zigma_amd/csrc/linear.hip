@@ -353,6 +353,9 @@ int launch_linear4w(const zigma_linear_params_t &p, hipStream_t stream);
 // csrc/linear_ws.hip: weights stationary in registers, only the tokens stream (k <= 640, n % 256 == 0)
 bool linear_ws_eligible(const zigma_linear_params_t &p);
 int launch_linear_ws(const zigma_linear_params_t &p, hipStream_t stream);
+// csrc/linear_sm.hip: few tokens — tiles of 128 tokens x n / 4 features (n % 160 == 0 or n % 192 == 0), one per workgroup
+bool linear_sm_eligible(const zigma_linear_params_t &p);
+int launch_linear_sm(const zigma_linear_params_t &p, hipStream_t stream);
 
 }  // namespace zigma
 
@@ -363,7 +366,7 @@ extern "C" int zigma_linear_fwd(const zigma_linear_params_t *pp, void *stream_) 
     (void)hipGetLastError();
     const zigma_linear_params_t &p = *pp;
     if (p.m < 0 || p.n < 1 || p.k < 1) return ZIGMA_ERR_SHAPE;
-    if (p.flags & ~0xf77f00) return ZIGMA_ERR_UNSUPPORTED;     // 0x4000: the weight-stationary kernel; 0x100 ... 0x1000: timing / A-B probes (tools/linear_probe.py); 0x2000: the 8-wave kernel; 0x10000 .. 0x50000: probes of the 4-wave kernel (probe builds only)
+    if (p.flags & ~0xf7ff00) return ZIGMA_ERR_UNSUPPORTED;     // 0x4000: the weight-stationary kernel; 0x8000: the few-token kernel; 0x100 ... 0x1000: timing / A-B probes (tools/linear_probe.py); 0x2000: the 8-wave kernel; 0x10000 .. 0x50000: probes of the 4-wave kernel (probe builds only)
     if (p.m == 0) return ZIGMA_OK;
     if (!p.x || !p.w || !p.out) return ZIGMA_ERR_NULL;
     if (p.dtype != ZIGMA_BF16) return ZIGMA_ERR_DTYPE;
@@ -385,6 +388,7 @@ extern "C" int zigma_linear_fwd(const zigma_linear_params_t *pp, void *stream_) 
     }
     if (p.bias && (p.n > 4096 || reinterpret_cast<uintptr_t>(p.bias) % 4 != 0)) return ZIGMA_ERR_SHAPE;
     if (p.flags & 0x4000) return linear_ws_eligible(p) ? launch_linear_ws(p, stream) : ZIGMA_ERR_UNSUPPORTED;
+    if (p.flags & 0x8000) return linear_sm_eligible(p) ? launch_linear_sm(p, stream) : ZIGMA_ERR_UNSUPPORTED;
     if (linear4w_eligible(p)) return launch_linear4w(p, stream);        // (needs flags == 0: any probe flag pins the 8-wave kernel)
     const bool wide = p.n % 256 == 0 && !(p.flags & 0x1000) && !p.residual;      // 0x1000: force the 256 x 128 tile (probe)
     const int tiles_n = p.n / (wide ? 256 : 128);

@@ -1,0 +1,175 @@
+// linear_sm: out = x @ W^T for FEW tokens (serving-size batches, the video model at B = 2), gfx950 — out_proj of the ZigMa block below the
+// token floor of the 4-wave tiled kernel.  Reference call site: selective_scan_interface.py:365 (F.linear).
+//
+// Why a third tile shape.  At 8192 tokens x 640 features the 256 x 128 tiles of linear_tn_kernel are 160 workgroups on 256 CUs, the
+// 256 x 256 tiles of linear4w 96; the weight-stationary kernel with 128-feature panels spends a third of its time loading its panel.  All
+// three lose to hipBLASLt there (27 / - / 25 us against 22; 48 / - / 37 against 34 at 16 384 tokens).  The product is small enough that tile
+// QUANTISATION decides: with tiles of 128 tokens x N / 4 features (160 at E = 640, 192 at E = 768) 8192 tokens are exactly 256 tiles — one
+// per CU, one round — and 16 384 tokens exactly two.
+//
+//   workgroup = 4 waves = one tile; wave w owns tokens [32 w, 32 w + 32) x all NBLK feature blocks of 32: NBLK accumulators of
+//   v_mfma_f32_32x32x16_bf16, evaluated transposed like the other projection kernels (D[n][m]: W rows are the A operand, tokens the B
+//   operand), so a lane ends up with 4 consecutive features of ONE token per accumulator quad.
+//   BK = 64, three LDS stages of (32 NBLK + 128) rows x 128 B filled by global_load_lds_dwordx4 two k-steps ahead (the bank swizzle
+//   — 16-byte slot ^= (row >> 1) & 7 — is applied to the per-lane SOURCE address and again on the fragment reads); ONE raw s_barrier
+//   per k-step behind a counted s_waitcnt vmcnt.
+//   Epilogue: accumulators -> bf16 -> the wave's LDS tile (32 tokens x 32 NBLK features, 16-byte padded pitch) -> 16-byte stores along
+//   the token rows.
+// Limits: bf16, no bias / activation / residual, k % 64 == 0 and k >= 128, m % 128 == 0, n % (32 NBLK) == 0 for NBLK = 5 or 6.
+#include "scan_helpers.h"
+
+namespace zigma {
+namespace lsm {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __attribute__((address_space(3))) unsigned char *lds_ptr_t;
+typedef const __attribute__((address_space(1))) void *gbl_ptr_t;
+
+constexpr int kBM = 128, kBK = 64, kNST = 3;
+
+template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+template <int NBLK>
+__global__ __launch_bounds__(256) void linear_sm_kernel(const zigma_linear_params_t p, const int tiles_n) {
+    constexpr int BN = 32 * NBLK, ROWS = BN + kBM, STAGE = ROWS * 128;        // bytes per stage: W rows first, then token rows
+    constexpr int NLD = ROWS / 32;                                            // direct-to-LDS loads per wave and stage (8 rows each, 4 waves)
+    constexpr int PITCH = BN * 2 + 16;                                        // epilogue tile: bytes per token row (padded)
+    static_assert(ROWS % 32 == 0, "whole load instructions");
+    static_assert(kNST * STAGE <= 160 * 1024 && 4 * 32 * PITCH <= kNST * STAGE, "LDS");
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[kNST * STAGE];   // ONE LDS object (cdna_hip_programming.md §5)
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int j = lane & 31, kh = lane >> 5;
+    // tile of this workgroup: consecutive workgroup ids go round the 8 XCDs, so XCD x takes the contiguous eighth [x T / 8, (x + 1) T / 8) of the
+    // (m-tile, n-tile) raster — the n-tiles of a token panel share one L2
+    int tile = blockIdx.x;
+    if ((gridDim.x & 7) == 0) tile = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+    const int mt = tile / tiles_n, nt = tile - mt * tiles_n;
+    const int nk = p.k / kBK;
+    const int64_t x_pitch = p.x_row_stride * 2, w_pitch = p.w_row_stride * 2, o_pitch = p.out_row_stride * 2;
+    const unsigned char *wb = reinterpret_cast<const unsigned char *>(p.w) + static_cast<int64_t>(nt) * BN * w_pitch;
+    const unsigned char *xb = reinterpret_cast<const unsigned char *>(p.x) + static_cast<int64_t>(mt) * kBM * x_pitch;
+
+    // staging: instruction i of wave w fills the 8 rows q * 8 .. q * 8 + 7, q = i * 4 + w, of the stage (lane -> row q * 8 + (lane >> 3),
+    // 16-byte piece lane & 7).  The source piece is swizzled by the row: (lane & 7) ^ ((row >> 1) & 7), row & 15 = (w & 1) * 8 + (lane >> 3).
+    const int srow = (wave & 1) * 8 + (lane >> 3);
+    const unsigned piece = static_cast<unsigned>(((lane & 7) ^ ((srow >> 1) & 7)) << 4);
+    auto issue = [&](int kt) {
+        unsigned char *dst = smem + (kt % kNST) * STAGE;
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) {
+            const int q = i * 4 + wave, row = q * 8 + (lane >> 3);               // row of the stage this lane's 16 bytes belong to
+            const unsigned char *src = row < BN ? wb + static_cast<int64_t>(row) * w_pitch : xb + static_cast<int64_t>(row - BN) * x_pitch;
+            __builtin_amdgcn_global_load_lds((gbl_ptr_t)(src + kt * (kBK * 2) + piece), (lds_ptr_t)(dst) + q * 1024, 16, 0, 0);
+        }
+    };
+    // fragment reads: row * 128 + (((ks << 1) | kh) ^ ((row >> 1) & 7)) * 16; every row base used here is a multiple of 32, so (row >> 1) & 7 = (j >> 1) & 7
+    const int sw = (j >> 1) & 7;
+    const int a_row0 = j * 128, b_row0 = (BN + wave * 32 + j) * 128;
+
+    f32x16 acc[NBLK];
+#pragma unroll
+    for (int nb = 0; nb < NBLK; ++nb) acc[nb] = f32x16{};
+
+    issue(0);
+    if (nk > 1) issue(1);
+#pragma unroll 1
+    for (int kt = 0; kt < nk; ++kt) {
+        // stage kt has landed when only the younger batch (if any) is outstanding — for this wave's parts; the barrier makes it true for all
+        if (kt + 1 < nk) wait_vm<NLD>(); else wait_vm<0>();
+        __builtin_amdgcn_s_barrier();                      // ... and every wave is done with stage kt - 1, which the next batch overwrites
+        if (kt + 2 < nk) issue(kt + 2);
+        const unsigned char *sb = smem + (kt % kNST) * STAGE;
+        // fragments one k-substep ahead of the MFMAs that use them: with one wave per SIMD nothing else covers an LDS round trip
+        bf16x8 fa[2][NBLK], fb[2];
+        auto frags = [&](int ks, bf16x8 (&a)[NBLK], bf16x8 &b) {
+            const int off = ((((ks << 1) | kh) ^ sw) << 4);
+            b = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4 *>(sb + b_row0 + off));
+#pragma unroll
+            for (int nb = 0; nb < NBLK; ++nb)
+                a[nb] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4 *>(sb + a_row0 + nb * 32 * 128 + off));
+        };
+        frags(0, fa[0], fb[0]);
+#pragma unroll
+        for (int ks = 0; ks < kBK / 16; ++ks) {
+            if (ks + 1 < kBK / 16) frags(ks + 1, fa[(ks + 1) & 1], fb[(ks + 1) & 1]);
+#pragma unroll
+            for (int nb = 0; nb < NBLK; ++nb)
+                acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[ks & 1][nb], fb[ks & 1], acc[nb], 0, 0, 0);
+        }
+        // pin the order hipcc would otherwise collapse to [reads -> wait -> MFMAs] per sub-step (masks: 0x100 DS read, 0x008 MFMA): the NBLK + 1
+        // reads of sub-step ks + 1 go out one by one between the MFMAs of sub-step ks (two behind the first)
+        {
+            __builtin_amdgcn_sched_group_barrier(0x100, NBLK + 1, 0);
+#pragma unroll
+            for (int ks = 0; ks + 1 < kBK / 16; ++ks) {
+#pragma unroll
+                for (int r = 0; r < NBLK; ++r) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    if (r == 0) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+                    else __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                }
+            }
+            __builtin_amdgcn_sched_group_barrier(0x008, NBLK, 0);
+        }
+    }
+    // ---- epilogue: D[i][jj], jj = token (lane & 31), i = feature = (r & 3) + 8 (r >> 2) + 4 (lane >> 5): the wave transposes its 32 x BN tile
+    // through LDS (the stages are free: barrier) and stores 16-byte pieces along the token rows
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    unsigned char *scr = smem + wave * (32 * PITCH);
+#pragma unroll
+    for (int nb = 0; nb < NBLK; ++nb)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            uint2 pk;
+            pk.x = static_cast<uint32_t>(from_float<BF16>(acc[nb][q * 4])) | (static_cast<uint32_t>(from_float<BF16>(acc[nb][q * 4 + 1])) << 16);
+            pk.y = static_cast<uint32_t>(from_float<BF16>(acc[nb][q * 4 + 2])) | (static_cast<uint32_t>(from_float<BF16>(acc[nb][q * 4 + 3])) << 16);
+            *reinterpret_cast<uint2 *>(scr + j * PITCH + (nb * 32 + q * 8 + kh * 4) * 2) = pk;
+        }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();                       // wave-private tile: writes and reads of one wave
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    constexpr int PPR = BN * 2 / 16;                       // 16-byte pieces per token row
+    unsigned char *ob = reinterpret_cast<unsigned char *>(p.out) + (static_cast<int64_t>(mt) * kBM + wave * 32) * o_pitch + static_cast<int64_t>(nt) * BN * 2;
+#pragma unroll
+    for (int it = 0; it < (32 * PPR + 63) / 64; ++it) {
+        const int idx = it * 64 + lane;
+        if (idx < 32 * PPR) {
+            const int tok = idx / PPR, pc = idx - tok * PPR;
+            const uint4 v = *reinterpret_cast<const uint4 *>(scr + tok * PITCH + pc * 16);
+            *reinterpret_cast<uint4 *>(ob + tok * o_pitch + pc * 16) = v;
+        }
+    }
+}
+
+}  // namespace lsm
+
+// feature blocks per tile (5: n % 160 == 0; 6: n % 192 == 0) the few-token kernel uses for the call, or 0 if it does not serve it
+static int linear_sm_blocks(const zigma_linear_params_t &p) {
+    if (p.bias || p.residual || p.silu_from_col < p.n) return 0;
+    if (p.k % 64 != 0 || p.k < 128 || p.m % 128 != 0 || p.m < 128) return 0;
+    if (p.out_row_stride % 8 != 0 || reinterpret_cast<uintptr_t>(p.out) % 16 != 0) return 0;
+    if (128 * p.x_row_stride * 2 > 0x7fffffff || 192 * p.w_row_stride * 2 > 0x7fffffff) return 0;
+    const int nblk = p.n % 160 == 0 ? 5 : p.n % 192 == 0 ? 6 : 0;
+    if (!nblk) return 0;
+    if ((p.m / 128) * (p.n / (32 * nblk)) > 0x7fffffff) return 0;
+    return nblk;
+}
+
+bool linear_sm_eligible(const zigma_linear_params_t &p) { return linear_sm_blocks(p) != 0; }
+
+int launch_linear_sm(const zigma_linear_params_t &p, hipStream_t stream) {
+    const int nblk = linear_sm_blocks(p);
+    if (!nblk) return ZIGMA_ERR_UNSUPPORTED;
+    const int tiles_n = p.n / (32 * nblk);
+    const dim3 grid(static_cast<unsigned>((p.m / 128) * tiles_n)), block(256);
+    if (nblk == 5) hipLaunchKernelGGL((lsm::linear_sm_kernel<5>), grid, block, 0, stream, p, tiles_n);
+    else hipLaunchKernelGGL((lsm::linear_sm_kernel<6>), grid, block, 0, stream, p, tiles_n);
+    set_last_kernel(nblk == 5 ? "linear_sm_128x160" : "linear_sm_128x192");
+    return check_launch();
+}
+
+}  // namespace zigma

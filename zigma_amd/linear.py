@@ -74,11 +74,26 @@ def linear_ws_eligible(x, weight, bias=None):
     return pw > 0 and n % pw == 0 and n <= 8192 and m % 512 == 0 and m // 512 >= 32 // (n // pw) and x.stride(-2) % 128 == 0
 
 
-def linear(x, weight, bias=None, silu_from_col=None, out=None, _probe_flags=0, residual=None, gate=None, weight_stationary=False):
+LINEAR_SM_FLAG = 0x8000          # zigma_linear_params_t.flags: ZIGMA_LINEAR_SM (csrc/linear_sm.hip)
+
+
+def linear_sm_eligible(x, weight, bias=None):
+    """limits of the few-token tiled kernel (csrc/linear_sm.hip: tiles of 128 tokens x n / 4 features, one per workgroup — 8192 tokens x 640
+    features are exactly 256 tiles): bf16, no bias, k % 64 == 0 and k >= 128, tokens % 128 == 0, n % 160 == 0 or n % 192 == 0 — on top of
+    linear_eligible's alignment rules."""
+    if bias is not None or not linear_eligible(x, weight, None, prefer_own=True):
+        return False
+    n, k = weight.shape
+    m = x.numel() // k
+    return k >= 128 and m % 128 == 0 and m >= 128 and (n % 160 == 0 or n % 192 == 0)
+
+
+def linear(x, weight, bias=None, silu_from_col=None, out=None, _probe_flags=0, residual=None, gate=None, weight_stationary=False, few_tokens=False):
     """out = x @ weight.T (+ bias); output columns >= silu_from_col (a multiple of 32) leave as silu(.).
     residual (same shape as the result) + gate (batch, n): out = residual + gate[b] * bf16(x @ weight.T + bias) in the kernel's
     epilogue (the gated branch add of the reference's Block, model_zigma.py:447-449); x must then be (batch, rows, k) with
-    rows % 256 == 0.  weight_stationary: the csrc/linear_ws.hip kernel (linear_ws_eligible shapes only; fails otherwise)."""
+    rows % 256 == 0.  weight_stationary: the csrc/linear_ws.hip kernel (linear_ws_eligible shapes only; fails otherwise); few_tokens: the
+    csrc/linear_sm.hip kernel (linear_sm_eligible shapes only)."""
     dev = _lib.require_device(x, weight, bias, out, residual, gate)
     lead, k = x.shape[:-1], x.shape[-1]
     x2 = x.reshape(-1, k)
@@ -87,7 +102,7 @@ def linear(x, weight, bias=None, silu_from_col=None, out=None, _probe_flags=0, r
         out = torch.empty(x2.shape[0], n, device=x.device, dtype=x.dtype)
     o2 = out if out.dim() == 2 else out.view(-1, n)            # a view: the kernel writes through the row pitch
     P = _lib.LinearParams()
-    P.m, P.n, P.k, P.dtype, P.flags = x2.shape[0], n, k, _lib.dtype_id(x), int(_probe_flags) | (LINEAR_WS_FLAG if weight_stationary else (0x2000 if FORCE_8W else 0))
+    P.m, P.n, P.k, P.dtype, P.flags = x2.shape[0], n, k, _lib.dtype_id(x), int(_probe_flags) | (LINEAR_WS_FLAG if weight_stationary else LINEAR_SM_FLAG if few_tokens else (0x2000 if FORCE_8W else 0))
     P.silu_from_col = n if silu_from_col is None else int(silu_from_col)
     P.x_row_stride, P.w_row_stride, P.out_row_stride = x2.stride(0), weight.stride(0), o2.stride(0)
     P.x, P.w, P.bias, P.out = _lib.ptr(x2), _lib.ptr(weight), _lib.ptr(bias), _lib.ptr(o2)

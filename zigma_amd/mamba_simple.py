@@ -17,7 +17,7 @@ import torch.nn.functional as F
 
 from . import _knobs
 from . import linear as _zl
-from .linear import gated_residual_eligible, linear, linear_eligible, linear_ws_eligible, routes_to_4w
+from .linear import gated_residual_eligible, linear, linear_eligible, linear_sm_eligible, linear_ws_eligible, routes_to_4w
 from .selective_scan_interface import mamba_inner_tok
 from .wgrad import linear_train
 
@@ -37,6 +37,9 @@ IN_PROJ_ONE_LAUNCH_K = 704
 # reference (selective_scan_fwd_kernel.cuh:293 applies silu in fp32 to the bf16 z).  Measured in round 5: see there for the default.
 # out_proj (k = 1280 / 1536) on the weight-stationary kernel's 128-feature-panel form below the tiled 4-wave kernel's token floor (round 5)
 OUT_PROJ_WS_MAX_TOKENS = 32768
+# ... on the few-token tiled kernel (csrc/linear_sm.hip) where it serves the shape; the 128-feature-panel weight-stationary form otherwise
+OUT_PROJ_FEW_TOKENS = True
+OUT_PROJ_FEW_MIN_TOKENS = 2048
 OUT_PROJ_FUSE_NEEDS_4W = True
 GATE_IN_IN_PROJ = False
 _knobs.apply(globals(), "mamba_simple")      # ZIGMA_KNOBS="mamba_simple.GATE_IN_IN_PROJ=True,..." (A/B tools)
@@ -295,6 +298,10 @@ class Mamba(nn.Module):
         if linear_eligible(x, lin.weight, lin.bias):
             return linear(x, lin.weight, lin.bias)
         n = lin.weight.shape[0]
+        if (OUT_PROJ_FEW_TOKENS and lin.bias is None and lin.weight.shape[1] > 640 and OUT_PROJ_FEW_MIN_TOKENS <= x.shape[:-1].numel() < OUT_PROJ_WS_MAX_TOKENS
+                and linear_sm_eligible(x, lin.weight)):
+            # out_proj below the 4-wave kernel's token floor: tiles of 128 tokens x n / 4 features, exactly one (8192 tokens) or two (16 384) per CU
+            return linear(x, lin.weight, few_tokens=True)
         if (IN_PROJ_WS and lin.bias is None and x.shape[:-1].numel() >= IN_PROJ_WS_MIN_TOKENS and linear_ws_eligible(x, lin.weight)
                 and (lin.weight.shape[1] <= 640 or x.shape[:-1].numel() < OUT_PROJ_WS_MAX_TOKENS)):
             # ONE launch, W_in panels resident in registers, only the tokens stream (half the L2 -> LDS bytes of the tiled kernel)
