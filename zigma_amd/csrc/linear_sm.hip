@@ -10,7 +10,7 @@
 //   workgroup = 4 waves = one tile; wave w owns tokens [32 w, 32 w + 32) x all NBLK feature blocks of 32: NBLK accumulators of
 //   v_mfma_f32_32x32x16_bf16, evaluated transposed like the other projection kernels (D[n][m]: W rows are the A operand, tokens the B
 //   operand), so a lane ends up with 4 consecutive features of ONE token per accumulator quad.
-//   BK = 64, three LDS stages of (32 NBLK + 128) rows x 128 B filled by global_load_lds_dwordx4 two k-steps ahead (the bank swizzle
+//   BK = 64, four LDS stages of (32 NBLK + 128) rows x 128 B filled by global_load_lds_dwordx4 three k-steps ahead (the bank swizzle
 //   — 16-byte slot ^= (row >> 1) & 7 — is applied to the per-lane SOURCE address and again on the fragment reads); ONE raw s_barrier
 //   per k-step behind a counted s_waitcnt vmcnt.
 //   Epilogue: accumulators -> bf16 -> the wave's LDS tile (32 tokens x 32 NBLK features, 16-byte padded pitch) -> 16-byte stores along
@@ -26,7 +26,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __attribute__((address_space(3))) unsigned char *lds_ptr_t;
 typedef const __attribute__((address_space(1))) void *gbl_ptr_t;
 
-constexpr int kBM = 128, kBK = 64, kNST = 3;
+constexpr int kBM = 128, kBK = 64, kNST = 4;       // four stages: loads three k-steps ahead (a direct-to-LDS load lands ~1.1 us after its issue)
 
 template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
@@ -75,12 +75,14 @@ __global__ __launch_bounds__(256) void linear_sm_kernel(const zigma_linear_param
 
     issue(0);
     if (nk > 1) issue(1);
+    if (nk > 2) issue(2);
 #pragma unroll 1
     for (int kt = 0; kt < nk; ++kt) {
-        // stage kt has landed when only the younger batch (if any) is outstanding — for this wave's parts; the barrier makes it true for all
-        if (kt + 1 < nk) wait_vm<NLD>(); else wait_vm<0>();
+        // stage kt has landed when only the younger batches (two, fewer at the end) are outstanding — for this wave's parts; the barrier makes
+        // it true for all
+        if (kt + 2 < nk) wait_vm<2 * NLD>(); else if (kt + 1 < nk) wait_vm<NLD>(); else wait_vm<0>();
         __builtin_amdgcn_s_barrier();                      // ... and every wave is done with stage kt - 1, which the next batch overwrites
-        if (kt + 2 < nk) issue(kt + 2);
+        if (kt + 3 < nk) issue(kt + 3);
         const unsigned char *sb = smem + (kt % kNST) * STAGE;
         // fragments one k-substep ahead of the MFMAs that use them: with one wave per SIMD nothing else covers an LDS round trip
         bf16x8 fa[2][NBLK], fb[2];
