@@ -56,14 +56,14 @@ __global__ __launch_bounds__(256) void linear_sm_kernel(const zigma_linear_param
     // 16-byte piece lane & 7).  The source piece is swizzled by the row: (lane & 7) ^ ((row >> 1) & 7), row & 15 = (w & 1) * 8 + (lane >> 3).
     const int srow = (wave & 1) * 8 + (lane >> 3);
     const unsigned piece = static_cast<unsigned>(((lane & 7) ^ ((srow >> 1) & 7)) << 4);
-    auto issue = [&](int kt) {
+    // one direct-to-LDS instruction: piece i of the batch of k-step kt -> its stage.  k-steps past the end are clamped to the last one: a harmless
+    // refill of a free stage that keeps the loop body branch-free and the counted wait uniform (the epilogue drains them before it reuses the LDS)
+    auto issue_piece = [&](int kt, int i) {
+        const int ks_src = kt < nk ? kt : nk - 1;
         unsigned char *dst = smem + (kt % kNST) * STAGE;
-#pragma unroll
-        for (int i = 0; i < NLD; ++i) {
-            const int q = i * 4 + wave, row = q * 8 + (lane >> 3);               // row of the stage this lane's 16 bytes belong to
-            const unsigned char *src = row < BN ? wb + static_cast<int64_t>(row) * w_pitch : xb + static_cast<int64_t>(row - BN) * x_pitch;
-            __builtin_amdgcn_global_load_lds((gbl_ptr_t)(src + kt * (kBK * 2) + piece), (lds_ptr_t)(dst) + q * 1024, 16, 0, 0);
-        }
+        const int q = i * 4 + wave, row = q * 8 + (lane >> 3);                  // row of the stage this lane's 16 bytes belong to
+        const unsigned char *src = row < BN ? wb + static_cast<int64_t>(row) * w_pitch : xb + static_cast<int64_t>(row - BN) * x_pitch;
+        __builtin_amdgcn_global_load_lds((gbl_ptr_t)(src + ks_src * (kBK * 2) + piece), (lds_ptr_t)(dst) + q * 1024, 16, 0, 0);
     };
     // fragment reads: row * 128 + (((ks << 1) | kh) ^ ((row >> 1) & 7)) * 16; every row base used here is a multiple of 32, so (row >> 1) & 7 = (j >> 1) & 7
     const int sw = (j >> 1) & 7;
@@ -73,18 +73,19 @@ __global__ __launch_bounds__(256) void linear_sm_kernel(const zigma_linear_param
 #pragma unroll
     for (int nb = 0; nb < NBLK; ++nb) acc[nb] = f32x16{};
 
-    issue(0);
-    if (nk > 1) issue(1);
-    if (nk > 2) issue(2);
+#pragma unroll
+    for (int b0 = 0; b0 < kNST - 1; ++b0)
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) issue_piece(b0, i);
+    constexpr int PPS = (NLD + 2) / 3;                      // pieces of the next batch per sub-step (sub-steps 0 .. 2)
 #pragma unroll 1
     for (int kt = 0; kt < nk; ++kt) {
-        // stage kt has landed when only the younger batches (two, fewer at the end) are outstanding — for this wave's parts; the barrier makes
-        // it true for all
-        if (kt + 2 < nk) wait_vm<2 * NLD>(); else if (kt + 1 < nk) wait_vm<NLD>(); else wait_vm<0>();
+        // stage kt has landed when only the two younger batches are outstanding — for this wave's parts; the barrier makes it true for all
+        wait_vm<2 * NLD>();
         __builtin_amdgcn_s_barrier();                      // ... and every wave is done with stage kt - 1, which the next batch overwrites
-        if (kt + 3 < nk) issue(kt + 3);
         const unsigned char *sb = smem + (kt % kNST) * STAGE;
-        // fragments one k-substep ahead of the MFMAs that use them: with one wave per SIMD nothing else covers an LDS round trip
+        // fragments one k-substep ahead of the MFMAs that use them, and the direct-to-LDS pieces of k-step kt + 3 spread between the MFMAs of the
+        // first three sub-steps: with one wave per SIMD nothing else covers an LDS round trip or the ~55 cycles a piece takes to issue
         bf16x8 fa[2][NBLK], fb[2];
         auto frags = [&](int ks, bf16x8 (&a)[NBLK], bf16x8 &b) {
             const int off = ((((ks << 1) | kh) ^ sw) << 4);
@@ -98,11 +99,13 @@ __global__ __launch_bounds__(256) void linear_sm_kernel(const zigma_linear_param
         for (int ks = 0; ks < kBK / 16; ++ks) {
             if (ks + 1 < kBK / 16) frags(ks + 1, fa[(ks + 1) & 1], fb[(ks + 1) & 1]);
 #pragma unroll
+            for (int i = ks * PPS; i < (ks + 1) * PPS && i < NLD && ks < 3; ++i) issue_piece(kt + kNST - 1, i);
+#pragma unroll
             for (int nb = 0; nb < NBLK; ++nb)
                 acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[ks & 1][nb], fb[ks & 1], acc[nb], 0, 0, 0);
         }
-        // pin the order hipcc would otherwise collapse to [reads -> wait -> MFMAs] per sub-step (masks: 0x100 DS read, 0x008 MFMA): the NBLK + 1
-        // reads of sub-step ks + 1 go out one by one between the MFMAs of sub-step ks (two behind the first)
+        // pin the order (masks: 0x100 DS read, 0x008 MFMA): behind every MFMA of sub-steps 0 .. 2 one fragment read of the next sub-step (two
+        // behind the first); the direct-to-LDS pieces stay where the source puts them, between the sub-steps
         {
             __builtin_amdgcn_sched_group_barrier(0x100, NBLK + 1, 0);
 #pragma unroll
@@ -117,6 +120,7 @@ __global__ __launch_bounds__(256) void linear_sm_kernel(const zigma_linear_param
             __builtin_amdgcn_sched_group_barrier(0x008, NBLK, 0);
         }
     }
+    wait_vm<0>();                                          // the refills past the end: they must not land in the epilogue's tiles
     // ---- epilogue: D[i][jj], jj = token (lane & 31), i = feature = (r & 3) + 8 (r >> 2) + 4 (lane >> 5): the wave transposes its 32 x BN tile
     // through LDS (the stages are free: barrier) and stores 16-byte pieces along the token rows
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
