@@ -164,9 +164,9 @@ def test_bench_block_path_vs_reference(variant, monkeypatch):
         elif variant == "in_proj_halves_b32":               # ... with in_proj as two half-width launches of the tiled kernel
             assert n_ws == 0 and n_in_halves == 2 * depth and n_lin == 5 * depth + 2, (n_in_halves, n_lin, counts)
         else:
-            # at 16 384 tokens in_proj is on the weight-stationary kernel, out_proj (unfused) on its 128-feature-panel form, + to_out
+            # at 16 384 tokens in_proj is on the weight-stationary kernel, out_proj (unfused) on the few-token tiled kernel, + to_out
             import zigma_amd.mamba_simple as zms
-            n_ws128 = counts.get(("zigma_linear_fwd", "linear_ws_128"), 0)
+            n_ws128 = counts.get(("zigma_linear_fwd", "linear_sm_128x160" if zms.OUT_PROJ_FEW_TOKENS else "linear_ws_128"), 0)      # (the few-token tiled kernel since the end of round 5)
             want128 = depth if zms.OUT_PROJ_WS_MAX_TOKENS > Bsz * 1024 else 0
             n_toq_ws = depth if mz.TO_Q_WS_MAX_TOKENS >= Bsz * 1024 else 0       # (8192: at 16 384 tokens to_q runs on the 8-wave tiled kernel)
             n_toq_own = depth if (n_toq_ws or mz.TO_Q_OWN_MIN_TOKENS <= Bsz * 1024) else 0

@@ -39,7 +39,7 @@ IN_PROJ_ONE_LAUNCH_K = 704
 OUT_PROJ_WS_MAX_TOKENS = 32768
 # ... on the few-token tiled kernel (csrc/linear_sm.hip) where it serves the shape; the 128-feature-panel weight-stationary form otherwise
 OUT_PROJ_FEW_TOKENS = True
-OUT_PROJ_FEW_MIN_TOKENS, OUT_PROJ_FEW_MAX_TOKENS = 2048, 8192      # (one round of tiles; at 16 384 tokens the 128-feature-panel form is faster: 37.6 against 40.8 us)
+OUT_PROJ_FEW_MIN_TOKENS = 2048      # (18.9 / 34.8 us at 8192 / 16 384 tokens, E = 640, against 22.4 / 34.7 for the library and 25.3 / 38.1 for the 128-feature-panel form)
 OUT_PROJ_FUSE_NEEDS_4W = True
 GATE_IN_IN_PROJ = False
 _knobs.apply(globals(), "mamba_simple")      # ZIGMA_KNOBS="mamba_simple.GATE_IN_IN_PROJ=True,..." (A/B tools)
@@ -298,9 +298,9 @@ class Mamba(nn.Module):
         if linear_eligible(x, lin.weight, lin.bias):
             return linear(x, lin.weight, lin.bias)
         n = lin.weight.shape[0]
-        if (OUT_PROJ_FEW_TOKENS and lin.bias is None and lin.weight.shape[1] > 640 and OUT_PROJ_FEW_MIN_TOKENS <= x.shape[:-1].numel() <= OUT_PROJ_FEW_MAX_TOKENS
+        if (OUT_PROJ_FEW_TOKENS and lin.bias is None and lin.weight.shape[1] > 640 and OUT_PROJ_FEW_MIN_TOKENS <= x.shape[:-1].numel() < OUT_PROJ_WS_MAX_TOKENS
                 and linear_sm_eligible(x, lin.weight)):
-            # out_proj at up to 8192 tokens: tiles of 128 tokens x n / 4 features, at most one per CU
+            # out_proj below the 4-wave kernel's token floor: tiles of 128 tokens x n / 4 features, exactly one (8192 tokens) or two (16 384) per CU
             return linear(x, lin.weight, few_tokens=True)
         if (IN_PROJ_WS and lin.bias is None and x.shape[:-1].numel() >= IN_PROJ_WS_MIN_TOKENS and linear_ws_eligible(x, lin.weight)
                 and (lin.weight.shape[1] <= 640 or x.shape[:-1].numel() < OUT_PROJ_WS_MAX_TOKENS)):
