@@ -497,7 +497,7 @@ int zigma_conv_x_proj_fwd(const zigma_conv_xproj_params_t *p, void *stream);
  * 128-column groups leave as silu(.) of the fp32 accumulator.
  * ZIGMA_LINEAR_SM (flags; round 5): the few-token tiled kernel (csrc/linear_sm.hip: tiles of 128 rows x n / 4 columns, one per workgroup —
  * 8192 rows x 640 columns are exactly 256 tiles).  Same result bit for bit.  Limits, else ZIGMA_ERR_UNSUPPORTED: no bias / activation /
- * residual, k % 64 == 0 and k >= 128, m % 128 == 0, n % 160 == 0 or n % 192 == 0, out rows 16-byte aligned.
+ * residual, k % 64 == 0 and k >= 128, m % 128 == 0 (n % 128 == 0: tiles of 160, 192 or 128 columns), out rows 16-byte aligned.
  * ------------------------------------------------------------------------------------------ */
 #define ZIGMA_LINEAR_WS 0x4000
 #define ZIGMA_LINEAR_SM 0x8000

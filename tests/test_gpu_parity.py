@@ -1107,7 +1107,7 @@ def test_linear_ws_silu_epilogue(M, K, N, col):
         linear(x, w, weight_stationary=True, silu_from_col=col + 64)
 
 
-@pytest.mark.parametrize("M,K,N", [(8192, 1280, 640), (16384, 1536, 768), (128, 128, 640), (384, 192, 768), (8192, 512, 640), (2048, 1280, 1920), (4096 + 128, 640, 1280)])
+@pytest.mark.parametrize("M,K,N", [(8192, 1280, 640), (16384, 1536, 768), (128, 128, 640), (384, 192, 768), (8192, 512, 640), (2048, 1280, 1920), (4096 + 128, 640, 1280), (8192, 640, 512), (16384, 640, 2560)])
 def test_linear_sm_kernel(M, K, N):
     """The few-token tiled projection kernel (csrc/linear_sm.hip, round 5: out_proj below the 4-wave kernel's token floor): sampled rows against
     float64 on the same bf16 operands; the WHOLE result bit-identical with the 8-wave tiled kernel (same MFMA, same accumulation order over k:
@@ -1119,7 +1119,7 @@ def test_linear_sm_kernel(M, K, N):
     w = (torch.randn(N, K, generator=g) * K ** -0.5).to(DEV, torch.bfloat16)
     assert linear_sm_eligible(x, w)
     y = linear(x, w, few_tokens=True)
-    assert _lib.last_kernel() == ("linear_sm_128x160" if N % 160 == 0 else "linear_sm_128x192") and y.shape == (M, N)
+    assert _lib.last_kernel() == ("linear_sm_128x160" if N % 160 == 0 else "linear_sm_128x192" if N % 192 == 0 else "linear_sm_128x128") and y.shape == (M, N)
     rows = torch.randint(0, M, (min(M, 1024),), generator=g).to(DEV)
     rows[:4] = torch.tensor([0, 31, 127, M - 1], device=DEV)
     ref = x[rows].double() @ w.double().T
@@ -1134,9 +1134,9 @@ def test_linear_sm_kernel(M, K, N):
     wide = torch.zeros(M, N + 256, device=DEV, dtype=torch.bfloat16)
     linear(x, w, out=wide[:, 128:128 + N], few_tokens=True)
     assert torch.equal(wide[:, 128:128 + N], y) and float(wide[:, :128].abs().max()) == 0 and float(wide[:, 128 + N:].abs().max()) == 0
-    assert not linear_sm_eligible(x[:104], w) and not linear_sm_eligible(x, w[:128])
+    assert not linear_sm_eligible(x[:104], w) and not linear_sm_eligible(x, w[:96])
     with pytest.raises(RuntimeError):
-        linear(x, w[:128], few_tokens=True)
+        linear(x[:104], w, few_tokens=True)
 
 
 def test_linear_ws_limits():

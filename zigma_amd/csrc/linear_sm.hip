@@ -15,7 +15,7 @@
 //   per k-step behind a counted s_waitcnt vmcnt.
 //   Epilogue: accumulators -> bf16 -> the wave's LDS tile (32 tokens x 32 NBLK features, 16-byte padded pitch) -> 16-byte stores along
 //   the token rows.
-// Limits: bf16, no bias / activation / residual, k % 64 == 0 and k >= 128, m % 128 == 0, n % (32 NBLK) == 0 for NBLK = 5 or 6.
+// Limits: bf16, no bias / activation / residual, k % 64 == 0 and k >= 128, m % 128 == 0, n % (32 NBLK) == 0 for NBLK = 5, 6 or 4 (tried in that order).
 #include "scan_helpers.h"
 
 namespace zigma {
@@ -153,13 +153,13 @@ __global__ __launch_bounds__(256) void linear_sm_kernel(const zigma_linear_param
 
 }  // namespace lsm
 
-// feature blocks per tile (5: n % 160 == 0; 6: n % 192 == 0) the few-token kernel uses for the call, or 0 if it does not serve it
+// feature blocks per tile (5: n % 160 == 0; 6: n % 192 == 0; 4: n % 128 == 0) the few-token kernel uses for the call, or 0 if it does not serve it
 static int linear_sm_blocks(const zigma_linear_params_t &p) {
     if (p.bias || p.residual || p.silu_from_col < p.n) return 0;
     if (p.k % 64 != 0 || p.k < 128 || p.m % 128 != 0 || p.m < 128) return 0;
     if (p.out_row_stride % 8 != 0 || reinterpret_cast<uintptr_t>(p.out) % 16 != 0) return 0;
     if (128 * p.x_row_stride * 2 > 0x7fffffff || 192 * p.w_row_stride * 2 > 0x7fffffff) return 0;
-    const int nblk = p.n % 160 == 0 ? 5 : p.n % 192 == 0 ? 6 : 0;
+    const int nblk = p.n % 160 == 0 ? 5 : p.n % 192 == 0 ? 6 : p.n % 128 == 0 ? 4 : 0;
     if (!nblk) return 0;
     if ((p.m / 128) * (p.n / (32 * nblk)) > 0x7fffffff) return 0;
     return nblk;
@@ -173,8 +173,9 @@ int launch_linear_sm(const zigma_linear_params_t &p, hipStream_t stream) {
     const int tiles_n = p.n / (32 * nblk);
     const dim3 grid(static_cast<unsigned>((p.m / 128) * tiles_n)), block(256);
     if (nblk == 5) hipLaunchKernelGGL((lsm::linear_sm_kernel<5>), grid, block, 0, stream, p, tiles_n);
-    else hipLaunchKernelGGL((lsm::linear_sm_kernel<6>), grid, block, 0, stream, p, tiles_n);
-    set_last_kernel(nblk == 5 ? "linear_sm_128x160" : "linear_sm_128x192");
+    else if (nblk == 6) hipLaunchKernelGGL((lsm::linear_sm_kernel<6>), grid, block, 0, stream, p, tiles_n);
+    else hipLaunchKernelGGL((lsm::linear_sm_kernel<4>), grid, block, 0, stream, p, tiles_n);
+    set_last_kernel(nblk == 5 ? "linear_sm_128x160" : nblk == 6 ? "linear_sm_128x192" : "linear_sm_128x128");
     return check_launch();
 }
 
