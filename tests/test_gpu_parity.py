@@ -1139,6 +1139,31 @@ def test_linear_sm_kernel(M, K, N):
         linear(x[:104], w, few_tokens=True)
 
 
+@pytest.mark.parametrize("Bsz,L,K,N,bias,res", [(8, 1024, 1280, 640, False, True), (16, 1024, 512, 640, True, True), (8, 1024, 1536, 768, False, True),
+                                                 (4, 512, 512, 640, True, False), (2, 256, 256, 1280, True, True)])
+def test_linear_sm_bias_and_gated_residual(Bsz, L, K, N, bias, res):
+    """The few-token kernel's epilogue (bias in fp32 before the single rounding; out = residual + gate[b] * bf16(x W^T + bias), reference Block
+    model_zigma.py:441-449): bit-identical with the 8-wave tiled kernel's (same arithmetic and rounding points) and against float64 on sampled rows."""
+    from zigma_amd import _lib
+    from zigma_amd.linear import linear, linear_sm_eligible
+    g = torch.Generator(device="cpu").manual_seed(Bsz + K + N + 3)
+    x = torch.randn(Bsz, L, K, generator=g).to(DEV, torch.bfloat16)
+    w = (torch.randn(N, K, generator=g) * K ** -0.5).to(DEV, torch.bfloat16)
+    b = (torch.randn(N, generator=g) * 0.2).to(DEV, torch.bfloat16) if bias else None
+    r = torch.randn(Bsz, L, N, generator=g).to(DEV, torch.bfloat16) if res else None
+    gt = torch.randn(Bsz, N, generator=g).to(DEV, torch.bfloat16) if res else None
+    assert linear_sm_eligible(x, w, b)
+    y = linear(x, w, b, residual=r, gate=gt, few_tokens=True)
+    assert _lib.last_kernel().startswith("linear_sm_128x")
+    y8 = linear(x, w, b, residual=r, gate=gt, _probe_flags=0x2000)
+    assert _lib.last_kernel().startswith("linear_tn_")
+    assert torch.equal(y, y8)
+    v = x.double() @ w.double().T + (b.double() if bias else 0)
+    ref = (r.double() + gt.double().unsqueeze(1) * v.bfloat16().double()) if res else v
+    assert float((y.double() - ref).norm() / ref.norm()) < 3e-3
+    assert torch.equal(linear(x, w, b, residual=r, gate=gt, few_tokens=True), y)
+
+
 def test_linear_ws_limits():
     from zigma_amd.linear import linear, linear_ws_eligible
     x = torch.randn(4096, 640, device=DEV).bfloat16()

@@ -15,7 +15,7 @@
 //   per k-step behind a counted s_waitcnt vmcnt.
 //   Epilogue: accumulators -> bf16 -> the wave's LDS tile (32 tokens x 32 NBLK features, 16-byte padded pitch) -> 16-byte stores along
 //   the token rows.
-// Limits: bf16, no bias / activation / residual, k % 64 == 0 and k >= 128, m % 128 == 0, n % (32 NBLK) == 0 for NBLK = 5, 6 or 4 (tried in that order).
+// Limits: bf16, no activation (bias and the gated residual: template flag EPI), k % 64 == 0 and k >= 128, m % 128 == 0, n % (32 NBLK) == 0 for NBLK = 5, 6 or 4 (tried in that order).
 #include "scan_helpers.h"
 
 namespace zigma {
@@ -30,7 +30,9 @@ constexpr int kBM = 128, kBK = 64, kNST = 4;       // four stages: loads three k
 
 template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
-template <int NBLK>
+// EPI: + bias (fp32, before the single rounding) and / or the block's gated branch add out = residual + gate[sample] * bf16(x W^T + bias) (reference
+// model_zigma.py:441-449) — the arithmetic and rounding points of linear_tn_kernel's epilogue (csrc/linear.hip), so the two agree bit for bit.
+template <int NBLK, bool EPI = false>
 __global__ __launch_bounds__(256) void linear_sm_kernel(const zigma_linear_params_t p, const int tiles_n) {
     constexpr int BN = 32 * NBLK, ROWS = BN + kBM, STAGE = ROWS * 128;        // bytes per stage: W rows first, then token rows
     constexpr int NLD = ROWS / 32;                                            // direct-to-LDS loads per wave and stage (8 rows each, 4 waves)
@@ -126,26 +128,57 @@ __global__ __launch_bounds__(256) void linear_sm_kernel(const zigma_linear_param
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     unsigned char *scr = smem + wave * (32 * PITCH);
+    const uint16_t *biasp = EPI ? reinterpret_cast<const uint16_t *>(p.bias) : nullptr;
 #pragma unroll
     for (int nb = 0; nb < NBLK; ++nb)
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
+            float v[4] = {acc[nb][q * 4], acc[nb][q * 4 + 1], acc[nb][q * 4 + 2], acc[nb][q * 4 + 3]};
+            if (EPI && biasp) {
+                const uint2 bq = *reinterpret_cast<const uint2 *>(biasp + nt * BN + nb * 32 + q * 8 + kh * 4);
+                v[0] += __uint_as_float(bq.x << 16);
+                v[1] += __uint_as_float(bq.x & 0xffff0000u);
+                v[2] += __uint_as_float(bq.y << 16);
+                v[3] += __uint_as_float(bq.y & 0xffff0000u);
+            }
             uint2 pk;
-            pk.x = static_cast<uint32_t>(from_float<BF16>(acc[nb][q * 4])) | (static_cast<uint32_t>(from_float<BF16>(acc[nb][q * 4 + 1])) << 16);
-            pk.y = static_cast<uint32_t>(from_float<BF16>(acc[nb][q * 4 + 2])) | (static_cast<uint32_t>(from_float<BF16>(acc[nb][q * 4 + 3])) << 16);
+            pk.x = static_cast<uint32_t>(from_float<BF16>(v[0])) | (static_cast<uint32_t>(from_float<BF16>(v[1])) << 16);
+            pk.y = static_cast<uint32_t>(from_float<BF16>(v[2])) | (static_cast<uint32_t>(from_float<BF16>(v[3])) << 16);
             *reinterpret_cast<uint2 *>(scr + j * PITCH + (nb * 32 + q * 8 + kh * 4) * 2) = pk;
         }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();                       // wave-private tile: writes and reads of one wave
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     constexpr int PPR = BN * 2 / 16;                       // 16-byte pieces per token row
-    unsigned char *ob = reinterpret_cast<unsigned char *>(p.out) + (static_cast<int64_t>(mt) * kBM + wave * 32) * o_pitch + static_cast<int64_t>(nt) * BN * 2;
+    const int64_t row0 = static_cast<int64_t>(mt) * kBM + wave * 32;
+    unsigned char *ob = reinterpret_cast<unsigned char *>(p.out) + row0 * o_pitch + static_cast<int64_t>(nt) * BN * 2;
+    // gated residual: the 128-token tile lies inside one sample (rows_per_batch % 256 == 0): one gate row
+    const unsigned char *rb = nullptr, *gb = nullptr;
+    int64_t r_pitch = 0;
+    if (EPI && p.residual) {
+        r_pitch = p.res_row_stride * 2;
+        rb = reinterpret_cast<const unsigned char *>(p.residual) + row0 * r_pitch + static_cast<int64_t>(nt) * BN * 2;
+        gb = reinterpret_cast<const unsigned char *>(p.gate) + ((static_cast<int64_t>(mt) * kBM) / p.rows_per_batch) * p.gate_batch_stride * 2 + static_cast<int64_t>(nt) * BN * 2;
+    }
 #pragma unroll
     for (int it = 0; it < (32 * PPR + 63) / 64; ++it) {
         const int idx = it * 64 + lane;
         if (idx < 32 * PPR) {
             const int tok = idx / PPR, pc = idx - tok * PPR;
-            const uint4 v = *reinterpret_cast<const uint4 *>(scr + tok * PITCH + pc * 16);
+            uint4 v = *reinterpret_cast<const uint4 *>(scr + tok * PITCH + pc * 16);
+            if (EPI && rb) {
+                const uint4 rs = *reinterpret_cast<const uint4 *>(rb + tok * r_pitch + pc * 16);
+                const uint4 gt = *reinterpret_cast<const uint4 *>(gb + pc * 16);
+                const unsigned vv[4] = {v.x, v.y, v.z, v.w}, rr[4] = {rs.x, rs.y, rs.z, rs.w}, gg[4] = {gt.x, gt.y, gt.z, gt.w};
+                unsigned oo[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float lo = __builtin_fmaf(__uint_as_float(gg[e] << 16), __uint_as_float(vv[e] << 16), __uint_as_float(rr[e] << 16));
+                    const float hi = __builtin_fmaf(__uint_as_float(gg[e] & 0xffff0000u), __uint_as_float(vv[e] & 0xffff0000u), __uint_as_float(rr[e] & 0xffff0000u));
+                    oo[e] = static_cast<uint32_t>(from_float<BF16>(lo)) | (static_cast<uint32_t>(from_float<BF16>(hi)) << 16);
+                }
+                v = make_uint4(oo[0], oo[1], oo[2], oo[3]);
+            }
             *reinterpret_cast<uint4 *>(ob + tok * o_pitch + pc * 16) = v;
         }
     }
@@ -155,10 +188,14 @@ __global__ __launch_bounds__(256) void linear_sm_kernel(const zigma_linear_param
 
 // feature blocks per tile (5: n % 160 == 0; 6: n % 192 == 0; 4: n % 128 == 0) the few-token kernel uses for the call, or 0 if it does not serve it
 static int linear_sm_blocks(const zigma_linear_params_t &p) {
-    if (p.bias || p.residual || p.silu_from_col < p.n) return 0;
+    if (p.silu_from_col < p.n) return 0;
     if (p.k % 64 != 0 || p.k < 128 || p.m % 128 != 0 || p.m < 128) return 0;
     if (p.out_row_stride % 8 != 0 || reinterpret_cast<uintptr_t>(p.out) % 16 != 0) return 0;
     if (128 * p.x_row_stride * 2 > 0x7fffffff || 192 * p.w_row_stride * 2 > 0x7fffffff) return 0;
+    if (p.bias && reinterpret_cast<uintptr_t>(p.bias) % 8 != 0) return 0;
+    if (p.residual) {       // (zigma_linear_fwd has checked pointers, pitches and rows_per_batch % 256 == 0 already)
+        if (!p.gate || p.rows_per_batch % 128 != 0) return 0;
+    }
     const int nblk = p.n % 160 == 0 ? 5 : p.n % 192 == 0 ? 6 : p.n % 128 == 0 ? 4 : 0;
     if (!nblk) return 0;
     if ((p.m / 128) * (p.n / (32 * nblk)) > 0x7fffffff) return 0;
@@ -172,9 +209,11 @@ int launch_linear_sm(const zigma_linear_params_t &p, hipStream_t stream) {
     if (!nblk) return ZIGMA_ERR_UNSUPPORTED;
     const int tiles_n = p.n / (32 * nblk);
     const dim3 grid(static_cast<unsigned>((p.m / 128) * tiles_n)), block(256);
-    if (nblk == 5) hipLaunchKernelGGL((lsm::linear_sm_kernel<5>), grid, block, 0, stream, p, tiles_n);
-    else if (nblk == 6) hipLaunchKernelGGL((lsm::linear_sm_kernel<6>), grid, block, 0, stream, p, tiles_n);
-    else hipLaunchKernelGGL((lsm::linear_sm_kernel<4>), grid, block, 0, stream, p, tiles_n);
+    const bool epi = p.bias || p.residual;
+#define ZIGMA_LSM(N_) do { if (epi) hipLaunchKernelGGL((lsm::linear_sm_kernel<N_, true>), grid, block, 0, stream, p, tiles_n); \
+                           else hipLaunchKernelGGL((lsm::linear_sm_kernel<N_, false>), grid, block, 0, stream, p, tiles_n); } while (0)
+    if (nblk == 5) ZIGMA_LSM(5); else if (nblk == 6) ZIGMA_LSM(6); else ZIGMA_LSM(4);
+#undef ZIGMA_LSM
     set_last_kernel(nblk == 5 ? "linear_sm_128x160" : nblk == 6 ? "linear_sm_128x192" : "linear_sm_128x128");
     return check_launch();
 }

@@ -79,13 +79,16 @@ LINEAR_SM_FLAG = 0x8000          # zigma_linear_params_t.flags: ZIGMA_LINEAR_SM 
 
 def linear_sm_eligible(x, weight, bias=None):
     """limits of the few-token tiled kernel (csrc/linear_sm.hip: tiles of 128 tokens x n / 4 features, one per workgroup — 8192 tokens x 640
-    features are exactly 256 tiles): bf16, no bias, k % 64 == 0 and k >= 128, tokens % 128 == 0 (tiles of 160, 192 or 128 features) — on top of
-    linear_eligible's alignment rules."""
-    if bias is not None or not linear_eligible(x, weight, None, prefer_own=True):
+    features are exactly 256 tiles): bf16, k % 64 == 0 and k >= 128, tokens % 128 == 0 (tiles of 160, 192 or 128 features), an optional bf16
+    bias on an 8-byte boundary — on top of linear_eligible's alignment rules.  The gated residual epilogue: gated_residual_eligible, as for the
+    tiled kernels."""
+    if not linear_eligible(x, weight, bias, fused_epilogue=True, prefer_own=True):
+        return False
+    if bias is not None and bias.data_ptr() % 8:
         return False
     n, k = weight.shape
     m = x.numel() // k
-    return k >= 128 and m % 128 == 0 and m >= 128        # (n % 128 == 0 by linear_eligible: tiles of 160, 192 or 128 features)
+    return k >= 128 and m % 128 == 0 and m >= 128        # (n % 128 == 0 by linear_eligible)
 
 
 def linear(x, weight, bias=None, silu_from_col=None, out=None, _probe_flags=0, residual=None, gate=None, weight_stationary=False, few_tokens=False):

@@ -177,8 +177,14 @@ class Mamba(nn.Module):
             return self._proj(y, lin)
         if (not torch.is_grad_enabled() and linear_eligible(y, lin.weight, lin.bias, fused_epilogue=True)
                 and gated_residual_eligible(y, residual, gate)):
-            return linear(y, lin.weight, lin.bias, residual=residual, gate=gate)
+            # (below the 4-wave kernel's token floor: the few-token tiled kernel carries the same epilogue)
+            return linear(y, lin.weight, lin.bias, residual=residual, gate=gate, few_tokens=self._few_tokens(y, lin))
         return torch.addcmul(residual, gate.unsqueeze(1), self._proj(y, lin))
+
+    @staticmethod
+    def _few_tokens(y, lin):
+        tokens = y.shape[:-1].numel()
+        return bool(OUT_PROJ_FEW_TOKENS and OUT_PROJ_FEW_MIN_TOKENS <= tokens < OUT_PROJ_WS_MAX_TOKENS and linear_sm_eligible(y, lin.weight, lin.bias))
 
     def out_add_fusable(self, residual, gate):
         """True when forward(..., residual=, gate=) will carry the gated add in out_proj's epilogue (no-grad, bf16, 256-row samples)"""
@@ -189,7 +195,9 @@ class Mamba(nn.Module):
         # (round 5: only where the 4-wave kernel takes the product — below its 256-tile floor the fused call runs on the 8-wave kernel, 48 us at
         # 16 384 tokens against 34 for the library + the add inside the next norm kernel, profiles/r05_b_shapes_probe.jsonl)
         tokens = residual.shape[1] * residual.shape[0]
-        return (tokens >= 16384 and (routes_to_4w(tokens, lin.weight.shape[0], self.d_inner) or not OUT_PROJ_FUSE_NEEDS_4W or _zl.LINEAR_POLICY == "all")
+        few = (OUT_PROJ_FEW_TOKENS and OUT_PROJ_FEW_MIN_TOKENS <= tokens < OUT_PROJ_WS_MAX_TOKENS and tokens % 128 == 0 and self.d_inner % 64 == 0
+               and self.d_inner >= 128)       # (the few-token tiled kernel carries the gated add too: end of round 5)
+        return ((few or (tokens >= 16384 and (routes_to_4w(tokens, lin.weight.shape[0], self.d_inner) or not OUT_PROJ_FUSE_NEEDS_4W or _zl.LINEAR_POLICY == "all")))
                 and lin.weight.dtype == torch.bfloat16 and self.d_inner % 64 == 0
                 and lin.weight.shape[0] % 128 == 0 and gated_residual_eligible(y, residual, gate)
                 and (lin.bias is None or lin.bias.dtype == torch.bfloat16))

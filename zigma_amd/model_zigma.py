@@ -32,7 +32,7 @@ from torch import Tensor
 from .attention import attention_math, cross_attn, cross_attn_eligible, cross_attn_train
 from . import embed as _embed
 from .layernorm import RMSNorm, block_norm, glue_bwd_eligible, layer_norm_fn, rms_norm_fn, scale_reduce_bwd
-from .linear import gated_residual_eligible, linear, linear_eligible, linear_ws_eligible
+from .linear import gated_residual_eligible, linear, linear_eligible, linear_sm_eligible, linear_ws_eligible
 from .mamba_simple import Mamba
 from .wgrad import linear_train
 from .scan_paths import hilbert_path, reverse_permut_np, zigzag_path
@@ -126,11 +126,13 @@ class CrossAttention(nn.Module):
 
     @staticmethod
     def _proj(x, lin):
-        # to_q on the weight-stationary kernel at 8192 tokens: 17.3 us against 21.1 for the library and 20.8 for the 8-wave kernel stand-alone
-        # (profiles/r05_b_shapes_probe.jsonl), 5.6-5.9 against 6.0 ms per B = 8 forward; at 16 384 tokens stand-alone 20.7 against 21.9 but the
-        # forward LOSES 3 % with it (7.49 against 7.27 ms, profiles/r05_d_small_batch_ab.jsonl), and from 32 768 on it ties the 4-wave kernel (r4)
-        if (lin.bias is None and not (torch.is_grad_enabled() and (x.requires_grad or lin.weight.requires_grad))
-                and (TO_Q_WS or x.shape[:-1].numel() <= TO_Q_WS_MAX_TOKENS) and linear_ws_eligible(x, lin.weight)):
+        # to_q below the 4-wave kernel's token floor (< 32 768 tokens) on the few-token tiled kernel (csrc/linear_sm.hip: 128 tokens x 128 features
+        # per workgroup — 8192 tokens are exactly 256 tiles): 11.5 / 19.0 us at 8192 / 16 384 tokens against 19.8 / 20.2 for the library, 17.2 / 21.3
+        # for the weight-stationary kernel and 20.9 / 23.8 for the 8-wave kernel (profiles/r05_l_shapes_probe_linear_sm_128.jsonl)
+        no_grad = not (torch.is_grad_enabled() and (x.requires_grad or lin.weight.requires_grad))
+        if (TO_Q_FEW_TOKENS and lin.bias is None and no_grad and TO_Q_FEW_MIN_TOKENS <= x.shape[:-1].numel() < 32768 and linear_sm_eligible(x, lin.weight)):
+            return linear(x, lin.weight, few_tokens=True)
+        if (lin.bias is None and no_grad and (TO_Q_WS or x.shape[:-1].numel() <= TO_Q_WS_MAX_TOKENS) and linear_ws_eligible(x, lin.weight)):
             return linear(x, lin.weight, weight_stationary=True)
         if linear_eligible(x, lin.weight, lin.bias):
             return linear(x, lin.weight, lin.bias)
@@ -148,7 +150,8 @@ class CrossAttention(nn.Module):
         if residual is None:
             return self.to_out[1](self._proj(o, lin))
         if not self.training and linear_eligible(o, lin.weight, lin.bias) and gated_residual_eligible(o, residual, gate):
-            return linear(o, lin.weight, lin.bias, residual=residual, gate=gate)
+            few = TO_Q_FEW_TOKENS and TO_Q_FEW_MIN_TOKENS <= o.shape[:-1].numel() < 32768 and linear_sm_eligible(o, lin.weight, lin.bias)
+            return linear(o, lin.weight, lin.bias, residual=residual, gate=gate, few_tokens=bool(few))
         return torch.addcmul(residual, gate.unsqueeze(1), self.to_out[1](self._proj(o, lin)))
 
     def forward(self, x, text, mask=None, kv=None, residual=None, gate=None):
@@ -288,6 +291,7 @@ class Pending:
 # pre-attention add + norm 68 -> 47, and with to_out's gated add: to_out 63 -> 78, pre-mixer add + norm 119 -> 102 — time moves from
 # the HBM-bound norm kernels into the projection epilogues, the forward is 0.1-0.3 % faster.
 TEXT_PROJ_OWN = os.environ.get("ZIGMA_TEXT_PROJ_OWN", "1") == "1"
+TO_Q_FEW_TOKENS, TO_Q_FEW_MIN_TOKENS = True, 2048
 TO_Q_WS_MAX_TOKENS = 8192
 TO_Q_OWN_MIN_TOKENS = 8192
 TO_Q_WS = os.environ.get("ZIGMA_TO_Q_WS", "0") == "1"      # to_q on the weight-stationary kernel (A/B knob: a tie stand-alone)   # y_embedder and the batched K / V projection of all blocks (B x 77 text rows) on zigma_linear_fwd, rows padded to 256
