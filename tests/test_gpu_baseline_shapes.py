@@ -155,18 +155,19 @@ def test_bench_block_path_vs_reference(variant, monkeypatch):
         n_zact = sum(1 for fn, _, P in trace if fn == "zigma_selective_scan_fwd" and (P.flags & _lib.SCAN_Z_PREACTIVATED))
         assert n_ws_silu == depth and n_ws == 0 and n_zact == depth and dt_in_scan == depth and gated == 2 * depth, (n_ws_silu, n_ws, n_zact, counts)
     elif variant in ("default", "default_b32", "in_proj_halves_b32"):
-        # out_proj + to_out carry their gated adds, every block (at 16 384 tokens on the few-token tiled kernel, end of round 5)
-        assert gated == 2 * depth, (gated, counts)
+        # out_proj + to_out carry their gated adds, every block; at 16 384 tokens (round 5) out_proj's add rides in the next norm kernel
+        # instead: below the 4-wave kernel's tile floor the plain product + that add are faster than the fused 8-wave call
+        assert gated == (depth if variant == "default" else 2 * depth), (gated, counts)
         assert n_text == 2, (n_text, counts)                # no library GEMM on the text side either
         if variant == "default_b32":                        # every projection of the block loop on an own kernel: in_proj (weight-stationary) + out_proj + to_q + to_out
             assert n_ws == depth and n_in_halves == 0 and n_lin == 4 * depth + 2, (n_ws, n_in_halves, n_lin, counts)
         elif variant == "in_proj_halves_b32":               # ... with in_proj as two half-width launches of the tiled kernel
             assert n_ws == 0 and n_in_halves == 2 * depth and n_lin == 5 * depth + 2, (n_in_halves, n_lin, counts)
         else:
-            # at 16 384 tokens: in_proj on the weight-stationary kernel; to_q, out_proj + add and to_out + bias + add on the few-token tiled kernel
-            # (tiles of 128 tokens x 128 / 160 features, two per CU) — no library GEMM in the block loop
-            n_sm128, n_sm160 = counts.get(("zigma_linear_fwd", "linear_sm_128x128"), 0), counts.get(("zigma_linear_fwd", "linear_sm_128x160"), 0)
-            assert n_ws == depth and n_sm128 == depth and n_sm160 == 2 * depth and n_lin == 4 * depth + 2, (n_ws, n_sm128, n_sm160, n_lin, counts)
+            # at 16 384 tokens: in_proj on the weight-stationary kernel, out_proj (unfused) on its 128-feature-panel form, to_q and to_out + bias + add on
+            # the 8-wave tiled kernel (the few-token tiled kernel serves up to 8192 tokens) — no library GEMM in the block loop
+            n_ws128 = counts.get(("zigma_linear_fwd", "linear_ws_128"), 0)
+            assert n_ws == depth and n_ws128 == depth and n_lin == 4 * depth + 2, (n_ws, n_ws128, n_lin, counts)
             assert not any(k.startswith("Cijk") for (_, k), _ in counts.items())
     elif variant == "unfused_out_proj":
         assert gated == depth, (gated, counts)              # to_out only

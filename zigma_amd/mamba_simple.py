@@ -39,7 +39,10 @@ IN_PROJ_ONE_LAUNCH_K = 704
 OUT_PROJ_WS_MAX_TOKENS = 32768
 # ... on the few-token tiled kernel (csrc/linear_sm.hip) where it serves the shape; the 128-feature-panel weight-stationary form otherwise
 OUT_PROJ_FEW_TOKENS = True
-OUT_PROJ_FEW_MIN_TOKENS = 2048      # (18.9 / 34.8 us at 8192 / 16 384 tokens, E = 640, against 22.4 / 34.7 for the library and 25.3 / 38.1 for the 128-feature-panel form)
+# (stand-alone 18.9 / 34.8 us at 8192 / 16 384 tokens, E = 640, against 22.4 / 34.7 for the library and 25.3 / 38.1 for the 128-feature-panel form; in the
+# forward it pays up to 8192 tokens — ONE round of tiles: B = 8 4.64 against 4.81 ms under hipGraph — and loses at 16 384, two rounds of 144 KB workgroups:
+# 7.05 against 6.83 ms, profiles/r05_m_serving_latency_linear_sm.jsonl)
+OUT_PROJ_FEW_MIN_TOKENS, OUT_PROJ_FEW_MAX_TOKENS = 2048, 8192
 OUT_PROJ_FUSE_NEEDS_4W = True
 GATE_IN_IN_PROJ = False
 _knobs.apply(globals(), "mamba_simple")      # ZIGMA_KNOBS="mamba_simple.GATE_IN_IN_PROJ=True,..." (A/B tools)
@@ -184,7 +187,7 @@ class Mamba(nn.Module):
     @staticmethod
     def _few_tokens(y, lin):
         tokens = y.shape[:-1].numel()
-        return bool(OUT_PROJ_FEW_TOKENS and OUT_PROJ_FEW_MIN_TOKENS <= tokens < OUT_PROJ_WS_MAX_TOKENS and linear_sm_eligible(y, lin.weight, lin.bias))
+        return bool(OUT_PROJ_FEW_TOKENS and OUT_PROJ_FEW_MIN_TOKENS <= tokens <= OUT_PROJ_FEW_MAX_TOKENS and linear_sm_eligible(y, lin.weight, lin.bias))
 
     def out_add_fusable(self, residual, gate):
         """True when forward(..., residual=, gate=) will carry the gated add in out_proj's epilogue (no-grad, bf16, 256-row samples)"""
@@ -195,7 +198,7 @@ class Mamba(nn.Module):
         # (round 5: only where the 4-wave kernel takes the product — below its 256-tile floor the fused call runs on the 8-wave kernel, 48 us at
         # 16 384 tokens against 34 for the library + the add inside the next norm kernel, profiles/r05_b_shapes_probe.jsonl)
         tokens = residual.shape[1] * residual.shape[0]
-        few = (OUT_PROJ_FEW_TOKENS and OUT_PROJ_FEW_MIN_TOKENS <= tokens < OUT_PROJ_WS_MAX_TOKENS and tokens % 128 == 0 and self.d_inner % 64 == 0
+        few = (OUT_PROJ_FEW_TOKENS and OUT_PROJ_FEW_MIN_TOKENS <= tokens <= OUT_PROJ_FEW_MAX_TOKENS and tokens % 128 == 0 and self.d_inner % 64 == 0
                and self.d_inner >= 128)       # (the few-token tiled kernel carries the gated add too: end of round 5)
         return ((few or (tokens >= 16384 and (routes_to_4w(tokens, lin.weight.shape[0], self.d_inner) or not OUT_PROJ_FUSE_NEEDS_4W or _zl.LINEAR_POLICY == "all")))
                 and lin.weight.dtype == torch.bfloat16 and self.d_inner % 64 == 0
@@ -306,7 +309,7 @@ class Mamba(nn.Module):
         if linear_eligible(x, lin.weight, lin.bias):
             return linear(x, lin.weight, lin.bias)
         n = lin.weight.shape[0]
-        if (OUT_PROJ_FEW_TOKENS and lin.bias is None and lin.weight.shape[1] > 640 and OUT_PROJ_FEW_MIN_TOKENS <= x.shape[:-1].numel() < OUT_PROJ_WS_MAX_TOKENS
+        if (OUT_PROJ_FEW_TOKENS and lin.bias is None and lin.weight.shape[1] > 640 and OUT_PROJ_FEW_MIN_TOKENS <= x.shape[:-1].numel() <= OUT_PROJ_FEW_MAX_TOKENS
                 and linear_sm_eligible(x, lin.weight)):
             # out_proj below the 4-wave kernel's token floor: tiles of 128 tokens x n / 4 features, exactly one (8192 tokens) or two (16 384) per CU
             return linear(x, lin.weight, few_tokens=True)

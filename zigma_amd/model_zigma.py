@@ -126,11 +126,11 @@ class CrossAttention(nn.Module):
 
     @staticmethod
     def _proj(x, lin):
-        # to_q below the 4-wave kernel's token floor (< 32 768 tokens) on the few-token tiled kernel (csrc/linear_sm.hip: 128 tokens x 128 features
+        # to_q at up to 8192 tokens on the few-token tiled kernel (csrc/linear_sm.hip: 128 tokens x 128 features
         # per workgroup — 8192 tokens are exactly 256 tiles): 11.5 / 19.0 us at 8192 / 16 384 tokens against 19.8 / 20.2 for the library, 17.2 / 21.3
         # for the weight-stationary kernel and 20.9 / 23.8 for the 8-wave kernel (profiles/r05_l_shapes_probe_linear_sm_128.jsonl)
         no_grad = not (torch.is_grad_enabled() and (x.requires_grad or lin.weight.requires_grad))
-        if (TO_Q_FEW_TOKENS and lin.bias is None and no_grad and TO_Q_FEW_MIN_TOKENS <= x.shape[:-1].numel() < 32768 and linear_sm_eligible(x, lin.weight)):
+        if (TO_Q_FEW_TOKENS and lin.bias is None and no_grad and TO_Q_FEW_MIN_TOKENS <= x.shape[:-1].numel() <= TO_Q_FEW_MAX_TOKENS and linear_sm_eligible(x, lin.weight)):
             return linear(x, lin.weight, few_tokens=True)
         if (lin.bias is None and no_grad and (TO_Q_WS or x.shape[:-1].numel() <= TO_Q_WS_MAX_TOKENS) and linear_ws_eligible(x, lin.weight)):
             return linear(x, lin.weight, weight_stationary=True)
@@ -150,7 +150,7 @@ class CrossAttention(nn.Module):
         if residual is None:
             return self.to_out[1](self._proj(o, lin))
         if not self.training and linear_eligible(o, lin.weight, lin.bias) and gated_residual_eligible(o, residual, gate):
-            few = TO_Q_FEW_TOKENS and TO_Q_FEW_MIN_TOKENS <= o.shape[:-1].numel() < 32768 and linear_sm_eligible(o, lin.weight, lin.bias)
+            few = TO_Q_FEW_TOKENS and TO_Q_FEW_MIN_TOKENS <= o.shape[:-1].numel() <= TO_Q_FEW_MAX_TOKENS and linear_sm_eligible(o, lin.weight, lin.bias)
             return linear(o, lin.weight, lin.bias, residual=residual, gate=gate, few_tokens=bool(few))
         return torch.addcmul(residual, gate.unsqueeze(1), self.to_out[1](self._proj(o, lin)))
 
@@ -291,7 +291,7 @@ class Pending:
 # pre-attention add + norm 68 -> 47, and with to_out's gated add: to_out 63 -> 78, pre-mixer add + norm 119 -> 102 — time moves from
 # the HBM-bound norm kernels into the projection epilogues, the forward is 0.1-0.3 % faster.
 TEXT_PROJ_OWN = os.environ.get("ZIGMA_TEXT_PROJ_OWN", "1") == "1"
-TO_Q_FEW_TOKENS, TO_Q_FEW_MIN_TOKENS = True, 2048
+TO_Q_FEW_TOKENS, TO_Q_FEW_MIN_TOKENS, TO_Q_FEW_MAX_TOKENS = True, 2048, 8192      # (to_q and to_out; one round of tiles: see mamba_simple.OUT_PROJ_FEW_MAX_TOKENS)
 TO_Q_WS_MAX_TOKENS = 8192
 TO_Q_OWN_MIN_TOKENS = 8192
 TO_Q_WS = os.environ.get("ZIGMA_TO_Q_WS", "0") == "1"      # to_q on the weight-stationary kernel (A/B knob: a tie stand-alone)   # y_embedder and the batched K / V projection of all blocks (B x 77 text rows) on zigma_linear_fwd, rows padded to 256
