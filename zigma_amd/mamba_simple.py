@@ -309,9 +309,9 @@ class Mamba(nn.Module):
         if linear_eligible(x, lin.weight, lin.bias):
             return linear(x, lin.weight, lin.bias)
         n = lin.weight.shape[0]
-        if (OUT_PROJ_FEW_TOKENS and lin.bias is None and lin.weight.shape[1] > 640 and OUT_PROJ_FEW_MIN_TOKENS <= x.shape[:-1].numel() <= OUT_PROJ_FEW_MAX_TOKENS
+        if (OUT_PROJ_FEW_TOKENS and lin.bias is None and lin.weight.shape[0] < lin.weight.shape[1] and OUT_PROJ_FEW_MIN_TOKENS <= x.shape[:-1].numel() <= OUT_PROJ_FEW_MAX_TOKENS
                 and linear_sm_eligible(x, lin.weight)):
-            # out_proj below the 4-wave kernel's token floor: tiles of 128 tokens x n / 4 features, exactly one (8192 tokens) or two (16 384) per CU
+            # out_proj (n < k: d_inner -> E) at up to 8192 tokens: tiles of 128 tokens x n / 4 features, at most one per CU
             return linear(x, lin.weight, few_tokens=True)
         if (IN_PROJ_WS and lin.bias is None and x.shape[:-1].numel() >= IN_PROJ_WS_MIN_TOKENS and linear_ws_eligible(x, lin.weight)
                 and (lin.weight.shape[1] <= 640 or x.shape[:-1].numel() < OUT_PROJ_WS_MAX_TOKENS)):
