@@ -43,6 +43,10 @@ OUT_PROJ_FEW_TOKENS = True
 # forward it pays up to 8192 tokens — ONE round of tiles: B = 8 4.64 against 4.81 ms under hipGraph — and loses at 16 384, two rounds of 144 KB workgroups:
 # 7.05 against 6.83 ms, profiles/r05_m_serving_latency_linear_sm.jsonl)
 OUT_PROJ_FEW_MIN_TOKENS, OUT_PROJ_FEW_MAX_TOKENS = 2048, 8192
+# the gated add in the few-token kernel's epilogue, or (False, the default) its plain product + the add inside the next norm kernel: the epilogue's residual rows
+# come cold from HBM with nothing on the CU to hide them — config 5 4.42-4.45 ms unfused against 4.53-4.55 fused under hipGraph, B = 8 a tie (4.78-4.81 both),
+# B = 16 +4 % fused (profiles/r05_p_few_token_fuse_ab.jsonl)
+OUT_PROJ_FEW_FUSE = False
 OUT_PROJ_FUSE_NEEDS_4W = True
 GATE_IN_IN_PROJ = False
 _knobs.apply(globals(), "mamba_simple")      # ZIGMA_KNOBS="mamba_simple.GATE_IN_IN_PROJ=True,..." (A/B tools)
@@ -198,7 +202,7 @@ class Mamba(nn.Module):
         # (round 5: only where the 4-wave kernel takes the product — below its 256-tile floor the fused call runs on the 8-wave kernel, 48 us at
         # 16 384 tokens against 34 for the library + the add inside the next norm kernel, profiles/r05_b_shapes_probe.jsonl)
         tokens = residual.shape[1] * residual.shape[0]
-        few = (OUT_PROJ_FEW_TOKENS and OUT_PROJ_FEW_MIN_TOKENS <= tokens <= OUT_PROJ_FEW_MAX_TOKENS and tokens % 128 == 0 and self.d_inner % 64 == 0
+        few = (OUT_PROJ_FEW_TOKENS and OUT_PROJ_FEW_FUSE and OUT_PROJ_FEW_MIN_TOKENS <= tokens <= OUT_PROJ_FEW_MAX_TOKENS and tokens % 128 == 0 and self.d_inner % 64 == 0
                and self.d_inner >= 128)       # (the few-token tiled kernel carries the gated add too: end of round 5)
         return ((few or (tokens >= 16384 and (routes_to_4w(tokens, lin.weight.shape[0], self.d_inner) or not OUT_PROJ_FUSE_NEEDS_4W or _zl.LINEAR_POLICY == "all")))
                 and lin.weight.dtype == torch.bfloat16 and self.d_inner % 64 == 0
