@@ -185,6 +185,40 @@ def test_bench_block_path_vs_reference(variant, monkeypatch):
     assert e_fp32 < 1.1 * ref_noise, (e_fp32, ref_noise)
 
 
+def test_serving_batch_block_path_vs_reference(monkeypatch):
+    """B = 8 (8192 tokens: the serving-size composition of round 5): the few-token tiled kernel serves to_q, out_proj (plain; its gated add
+    in the next norm kernel) and to_out + bias + add; in_proj runs weight-stationary, x_proj on its split-K form, the scan in sequence-split mode
+    — asserted from the call trace, no library GEMM in the block loop — and the two reference samples (batch positions 0 and 7) agree with
+    the reference's fp32 and bf16 outputs."""
+    from zigma_amd import _lib
+    m, g, cfg, y2 = _r2_model("r2_readme_b2", torch.bfloat16)
+    depth, Bsz = cfg["depth"], 8
+    gen = torch.Generator().manual_seed(98)
+    x = torch.randn(Bsz, *g["x"].shape[1:], generator=gen)
+    t = torch.rand(Bsz, generator=gen)
+    y = torch.rand(Bsz, *g["y"].shape[1:], generator=gen)
+    for pos, src in ((0, 0), (Bsz - 1, 1)):
+        x[pos], t[pos], y[pos] = torch.from_numpy(g["x"][src]), float(g["t"][src]), torch.from_numpy(g["y"][src])
+    trace = []
+    monkeypatch.setattr(_lib, "TRACE", trace)
+    with torch.no_grad():
+        out = m(x.to(DEV).bfloat16(), t.to(DEV).bfloat16(), y.to(DEV).bfloat16())
+    monkeypatch.setattr(_lib, "TRACE", None)
+    counts, gated = _trace_counts(trace)
+    c = lambda fn, k: counts.get((fn, k), 0)
+    assert c("zigma_linear_fwd", "linear_ws") == depth, counts                       # in_proj
+    assert c("zigma_linear_fwd", "linear_sm_128x128") == depth, counts               # to_q
+    assert c("zigma_linear_fwd", "linear_sm_128x160") == 2 * depth and gated == depth, (gated, counts)     # out_proj (plain) + to_out (fused)
+    assert c("zigma_x_proj_fwd", "x_proj_splitk") == depth, counts
+    assert sum(v for (fn, k), v in counts.items() if fn == "zigma_selective_scan_fwd" and k.startswith("scan_tok2")) == depth, counts
+    assert not any(k.startswith("Cijk") for (_, k), _ in counts.items())
+    got = N(out)[[0, Bsz - 1]]
+    ref_noise = float(g["ref_bf16_vs_fp32"])
+    e_fp32, e_bf16 = rel_err(got, g["out"]), rel_err(got, g["out_bf16"])
+    print(f"serving batch B={Bsz}: vs reference fp32 {e_fp32:.3e} (reference's own bf16: {ref_noise:.3e}), vs reference bf16 {e_bf16:.3e}")
+    assert np.isfinite(N(out)).all() and e_bf16 < 1e-2 and e_fp32 < 1.1 * ref_noise, (e_bf16, e_fp32, ref_noise)
+
+
 def test_no_text_block_path_trace_and_oracle(monkeypatch):
     """Blocks WITHOUT the attention branch (BASELINE config 3: unconditional, in_channels 4) at 32 768 tokens (from there on the 4-wave kernel
     takes the fused call; below, round 5 leaves the add to the next norm kernel): out_proj carries the
