@@ -89,6 +89,16 @@ class ScanTimer:
         return sum(a.elapsed_time(b) for a, b in self.pairs) / max(len(self.pairs), 1)
 
 
+def measured_valu_rates():
+    """(plain, packed, exp) ns per wave-instruction per SIMD from profiles/valu_rates_gfx950.json — the ONE place the measured issue rates live (the file
+    cites the micro-benchmark they come from); the literal fall-back is that file's content, for a checkout without profiles/"""
+    try:
+        r = json.load(open(os.path.join(ROOT, "profiles", "valu_rates_gfx950.json")))["ns_per_wave_instruction_per_simd"]
+        return float(r["plain_vop2"]), float(r["packed_f32_two_results"]), float(r["v_exp_f32"])
+    except (OSError, KeyError, ValueError):
+        return 1.35, 2.28, 3.43
+
+
 def pmc_traffic_live(limit_s=150):
     """HBM bytes per scan launch measured NOW: two rocprofv3 --pmc passes (FETCH_SIZE; WRITE_SIZE — they do not fit one pass) over
     tools/scan_one.py (the scan exactly as the model launches it at the headline shape), FETCH_SIZE doubled as
@@ -447,7 +457,8 @@ def main():
             # the same floor at the rates this chip sustains (tools/ubench2, profiles/r02_ubench2_valu_rates.txt: wall ns per
             # wave instruction per SIMD — v_exp_f32 3.43, v_pk_mul/fma_f32 2.28 for two results, plain VOP2 1.35): per 4 states
             # 4 exp + 6 packed + 4 plain = 32.8 ns
-            valu_floor_measured_us = groups / 4 * (4 * 3.43 + 6 * 2.28 + 4 * 1.35) * 1e-9 / 1024 * 1e6
+            rp, rk, re_ = measured_valu_rates()
+            valu_floor_measured_us = groups / 4 * (4 * re_ + 6 * rk + 4 * rp) * 1e-9 / 1024 * 1e6
             roof = dict(bound="hbm", kernel="scan_tok2 (fused zigzag selective scan" + (", dt_proj + softplus inside" if dt_in else "") + ")", achieved=ach / 1e9,
                         peak=HBM_PEAK / 1e9, unit="GB/s", frac=ach / HBM_PEAK, traffic=traffic,
                         traffic_source=traffic_src, launch_us=ms * 1e3, launches=len(timer.pairs), launches_bracketed="every %d-th of %d" % (timer.every, timer.count),
@@ -456,7 +467,7 @@ def main():
                         dt_proj_inside=bool(dt_in), limiter="valu", valu_floor_us=valu_floor_us,
                         valu_frac=valu_floor_us / (ms * 1e3), valu_floor_measured_rates_us=valu_floor_measured_us,
                         valu_frac_measured_rates=valu_floor_measured_us / (ms * 1e3),
-                        valu_rates_source="profiles/r02_ubench2_valu_rates.txt (tools/ubench2: ns per wave-instruction per SIMD)")
+                        valu_rates_source="profiles/valu_rates_gfx950.json <- profiles/r02_ubench2_valu_rates.txt (tools/ubench2: ns per wave-instruction per SIMD)")
         line = dict(metric="denoiser-forward latents/sec (BxL tokens/s), ZigMa d=640 L=32^2",
                     value=world * batch * L * args.steps / elapsed, unit="tokens/s", n_gpus=world, steps=args.steps,
                     warmup=args.warmup, ms_per_step=elapsed / args.steps * 1e3, higher_is_better=True, scaling="weak",

@@ -76,7 +76,8 @@ def config4(dev, dt, timer):
     # plain 1.35 per wave-instruction per SIMD): the full pass costs 4 exp + 6 packed + 4 plain per (step, 4 states) = 32.8 ns, the state-only
     # first pass 4 exp + 4 plain mul + 4 plain mul + 4 fma = 4 * 3.43 + 12 * 1.35 = 29.9 ns — the recurrence is evaluated twice
     groups = B * L * Di * N / 64 / 4
-    floor_us = groups * (32.8 + 29.9) * 1e-9 / 1024 * 1e6
+    rp, rk, re_ = bench.measured_valu_rates()                      # profiles/valu_rates_gfx950.json
+    floor_us = groups * ((4 * re_ + 6 * rk + 4 * rp) + (4 * re_ + 12 * rp)) * 1e-9 / 1024 * 1e6
     print(json.dumps(dict(config=4, what="L=16384 (4x128x128, patch 1), B=4, E=640 depth=18 zigzagN8: forward + scan kernel",
                           ms_per_forward=sec * 1e3, tokens_per_s=B * L / sec, scan_us=ms * 1e3, scan_algo_GBps=by / (ms * 1e-3) / 1e9,
                           scan_frac_of_8TBps=by / (ms * 1e-3) / 8e12, valu_floor_us=floor_us, valu_frac=floor_us / (ms * 1e3),
