@@ -14,6 +14,7 @@ from zigma_amd.selective_scan_interface import scan_raw
 
 BASE = os.path.join(ROOT, "tools", "libzigma_base_r04.so")
 NEW = _lib.LIB_PATH
+PROBE_NL = os.path.join(ROOT, "tools", "libzigma_probe_noload.so")      # optional: zigma_amd.build.build(lib=..., extra_flags=("-DZIGMA_SCAN_PROBE_NOLOAD",)) — the scan without its 16-bit row loads (timing probe, results wrong)
 _handles = {}
 
 
@@ -154,9 +155,10 @@ def scan_e768(name, lib, flags=0):
 
 PR = 1 << _lib.SCAN_PROBE_PRIO_SHIFT
 groups = {
-    "scan": {"r4": scan_dtp("s_r4", BASE), "r5": scan_dtp("s_r5", NEW), "r5_zact": scan_dtp("s_r5z", NEW, True)},
+    "scan": {"r4": scan_dtp("s_r4", BASE), "r5": scan_dtp("s_r5", NEW), "r5_zact": scan_dtp("s_r5z", NEW, True),
+             **({"r5_probe_no_row_loads": scan_dtp("s_nl", PROBE_NL)} if os.path.exists(PROBE_NL) else {})},
     "in_proj": {"r4": inproj(BASE), "r5": inproj(NEW), "r5_silu": inproj(NEW, True)},
-    "scan_b16": {"r4": scan_b16("b_r4", BASE), "r5": scan_b16("b_r5", NEW), "r5_dtproj_plus_split_512": scan_b16_split("b_s512", 512),
+    "scan_b16": {"r4": scan_b16("b_r4", BASE), "r5": scan_b16("b_r5", NEW), **({"r5_probe_no_row_loads": scan_b16("b_nl", PROBE_NL)} if os.path.exists(PROBE_NL) else {}), "r5_dtproj_plus_split_512": scan_b16_split("b_s512", 512),
                  "r5_dtproj_plus_split_256": scan_b16_split("b_s256", 256)},
     "scan_e768_b64": {"r4": scan_e768("g_r4", BASE), "r5_six_resident": scan_e768("g_r5", NEW), "r5_five_resident": scan_e768("g_r55", NEW, 1 << 10)},
     "scan_b8_split": {"r4": scan_b8("e_r4", BASE), "r5_rot": scan_b8("e_r5", NEW), "r5_norot": scan_b8("e_r5n", NEW, PR)},
