@@ -175,17 +175,17 @@ def check_against_unfused(model, x, t, y, out):
     """One forward of the SAME model through the unfused composition — library projections (no own MFMA kernel, no gated-add
     epilogue), the two-kernel conv / x_proj, the torch compositions of the embedding / conditioning / final-layer operators — outside the timed region: the timed path's output must be finite and agree
     norm-wise (bf16 model: the two compositions round at different points, ~5e-3)."""
-    import zigma_amd.linear as zl
+    import zigma_amd.routing as zr
     import zigma_amd.model_zigma as mz
     import zigma_amd.selective_scan_interface as ssi
     import zigma_amd.embed as ze
-    saved = (zl.LINEAR_POLICY, mz.FUSE_OUT_PROJ_ADD, mz.FUSE_OUT_PROJ_ADD_NO_TEXT, ssi.USE_CONV_X_PROJ, ze.USE_EMBED_KERNELS)
-    zl.LINEAR_POLICY, mz.FUSE_OUT_PROJ_ADD, mz.FUSE_OUT_PROJ_ADD_NO_TEXT, ssi.USE_CONV_X_PROJ, ze.USE_EMBED_KERNELS = "off", False, False, False, False
+    saved = (zr.POLICY, mz.FUSE_OUT_PROJ_ADD, mz.FUSE_OUT_PROJ_ADD_NO_TEXT, ssi.USE_CONV_X_PROJ, ze.USE_EMBED_KERNELS)
+    zr.POLICY, mz.FUSE_OUT_PROJ_ADD, mz.FUSE_OUT_PROJ_ADD_NO_TEXT, ssi.USE_CONV_X_PROJ, ze.USE_EMBED_KERNELS = "off", False, False, False, False
     try:
         with torch.no_grad():
             ref = model(x, t, y)
     finally:
-        zl.LINEAR_POLICY, mz.FUSE_OUT_PROJ_ADD, mz.FUSE_OUT_PROJ_ADD_NO_TEXT, ssi.USE_CONV_X_PROJ, ze.USE_EMBED_KERNELS = saved
+        zr.POLICY, mz.FUSE_OUT_PROJ_ADD, mz.FUSE_OUT_PROJ_ADD_NO_TEXT, ssi.USE_CONV_X_PROJ, ze.USE_EMBED_KERNELS = saved
     finite = bool(torch.isfinite(out).all())
     err = float((out.double() - ref.double()).norm() / ref.double().norm())
     if not finite or not err < 3e-2:

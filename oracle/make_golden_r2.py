@@ -6,6 +6,10 @@
   r2_video_t16     BASELINE configs[4] layer shapes: zzvideo_sst, E=768, 16 frames x 256 tokens, depth 3 (s, s, t), B=1
   r2_l16384        BASELINE configs[3] shape: 128x128 latents, patch 1 -> L=16384, E=640, zigzagN8 (N=128 tables), depth 2, B=1
   r2_small_video16 a tiny 16-frame model (T % 16 == 0 -> the no-copy temporal path) for quick runs
+  r6_zigzag8_e768  the SHIPPED image yaml's layer shapes (config/model/zigzag8_b1_pe2.yaml:4-10: 32x32x4 latents, patch 1, E=768, zigzagN8,
+                   use_pe 2), depth 3, B=2 — the E=768 routes (in_proj 768 -> 3072, x_proj K=1536, out_proj 1536 -> 768, the six-resident scan)
+  r6_sweep2_e768   the same with scan_type="v2" (config/model/sweep2_b1_pe2.yaml:4-10): forward + flipped scan per layer, two parameter sets
+                   (mamba_simple.py:304-339, selective_scan_interface.py:155-224)
 
 Each fixture holds the inputs and the reference's output in fp32 (`out`) AND the output of the reference's own bf16 run
 (`ZigMa(dtype=torch.bfloat16)`, bf16 inputs, `out_bf16`) — model_zigma.py:575,812-813.  Weights are not stored: both
@@ -38,6 +42,10 @@ CASES = {
     "r2_small_video16": dict(cfg=dict(in_channels=4, img_dim=8, embed_dim=64, depth=6, patch_size=2, num_classes=7,
                                       video_frames=16, scan_type="zzvideo_sst", use_pe=2, tpe=True),
                              x=(2, 16, 4, 8, 8), y=("class", 7), seed=24),
+    "r6_zigzag8_e768": dict(cfg=dict(in_channels=4, img_dim=32, embed_dim=768, depth=3, patch_size=1, scan_type="zigzagN8", use_pe=2),
+                            x=(2, 4, 32, 32), y=None, seed=61),
+    "r6_sweep2_e768": dict(cfg=dict(in_channels=4, img_dim=32, embed_dim=768, depth=3, patch_size=1, scan_type="v2", use_pe=2),
+                           x=(2, 4, 32, 32), y=None, seed=62),
 }
 
 

@@ -54,7 +54,7 @@ def _r2_model(name, dtype):
     return m, g, cfg, y
 
 
-R2 = ["r2_small_video16", "r2_readme_b2", "r2_video_t16", "r2_l16384"]
+R2 = ["r2_small_video16", "r2_readme_b2", "r2_video_t16", "r2_l16384", "r6_zigzag8_e768", "r6_sweep2_e768"]
 
 
 @pytest.mark.parametrize("name", R2)
@@ -105,7 +105,7 @@ def test_bench_block_path_vs_reference(variant, monkeypatch):
     positions 0 and B-1, the rest is noise; their rows are compared with the reference's fp32 and bf16 outputs.  Which
     kernels ran is asserted from the call trace.  Variants: the library out_proj + add inside the norm; every projection on
     the own kernel; none."""
-    import zigma_amd.linear as zl
+    import zigma_amd.routing as zr
     import zigma_amd.model_zigma as mz
     from zigma_amd import _lib
     m, g, cfg, y2 = _r2_model("r2_readme_b2", torch.bfloat16)
@@ -120,12 +120,11 @@ def test_bench_block_path_vs_reference(variant, monkeypatch):
     if variant == "unfused_out_proj":
         monkeypatch.setattr(mz, "FUSE_OUT_PROJ_ADD", False)
     elif variant == "linear_all":
-        monkeypatch.setattr(zl, "LINEAR_POLICY", "all")
+        monkeypatch.setattr(zr, "POLICY", "all")
     elif variant == "linear_off":
-        monkeypatch.setattr(zl, "LINEAR_POLICY", "off")
+        monkeypatch.setattr(zr, "POLICY", "off")
     elif variant == "in_proj_halves_b32":
-        import zigma_amd.mamba_simple as zms
-        monkeypatch.setattr(zms, "IN_PROJ_WS", False)
+        monkeypatch.setattr(zr, "DISABLED", {"in_proj.ws"})
     elif variant == "gate_in_in_proj_b32":                  # round 5: silu(z) written by in_proj's epilogue, the scan takes the gate as it finds it
         import zigma_amd.mamba_simple as zms
         monkeypatch.setattr(zms, "GATE_IN_IN_PROJ", True)
@@ -217,6 +216,116 @@ def test_serving_batch_block_path_vs_reference(monkeypatch):
     e_fp32, e_bf16 = rel_err(got, g["out"]), rel_err(got, g["out_bf16"])
     print(f"serving batch B={Bsz}: vs reference fp32 {e_fp32:.3e} (reference's own bf16: {ref_noise:.3e}), vs reference bf16 {e_bf16:.3e}")
     assert np.isfinite(N(out)).all() and e_bf16 < 1e-2 and e_fp32 < 1.1 * ref_noise, (e_bf16, e_fp32, ref_noise)
+
+
+class _LibraryGemms:
+    """records every F.linear / matmul-class library call the forward makes with >= `floor` rows (the block loop's projections): the _lib
+    trace only sees the C ABI, so "no library GEMM" is asserted from this list, not from kernel names"""
+
+    def __init__(self, monkeypatch, floor=2048):
+        import torch.nn.functional as F
+        self.calls = []
+        real = F.linear
+
+        def spy(x, w, b=None):
+            if x.numel() // max(x.shape[-1], 1) >= floor:
+                self.calls.append((x.numel() // x.shape[-1], w.shape[0], w.shape[1]))
+            return real(x, w, b)
+        monkeypatch.setattr(F, "linear", spy)
+
+
+def _embed_reference_samples(g, Bsz, seed, with_y=False):
+    gen = torch.Generator().manual_seed(seed)
+    x = torch.randn(Bsz, *g["x"].shape[1:], generator=gen)
+    t = torch.rand(Bsz, generator=gen)
+    for pos, src in ((0, 0), (Bsz - 1, 1)):
+        x[pos], t[pos] = torch.from_numpy(g["x"][src]), float(g["t"][src])
+    return x, t
+
+
+@pytest.mark.parametrize("Bsz", [8, 16, 64])
+@pytest.mark.parametrize("name", ["r6_zigzag8_e768", "r6_sweep2_e768"])
+def test_e768_block_path_vs_reference(name, Bsz, monkeypatch):
+    """The layer shapes of EVERY yaml the reference ships (config/model/zigzag8_b1_pe2.yaml:4-10, sweep2_b1_pe2.yaml:4-10: E = 768 -> d_inner 1536,
+    dt_rank 48, L = 1024) and both of their scan types — zigzagN8 and the bidirectional `v2` (mamba_simple.py:304-339: a second conv / x_proj /
+    dt_proj / A / D set on the flipped sequence, here a reversed row table) — at 8192 / 16 384 / 65 536 tokens so that every size gate of the
+    E = 768 routes opens.  The two samples of the reference run sit at batch positions 0 and B-1 of a noise batch; their
+    rows are compared with the reference's fp32 and bf16 outputs; which kernel served which projection is asserted from the call trace, and
+    the library GEMMs of the block loop are recorded (none expected)."""
+    import zigma_amd.routing as zr
+    from zigma_amd import _lib
+    m, g, cfg, _ = _r2_model(name, torch.bfloat16)
+    depth, E = cfg["depth"], cfg["embed_dim"]
+    v2 = cfg["scan_type"] == "v2"
+    tokens = Bsz * 1024
+    x, t = _embed_reference_samples(g, Bsz, 600 + Bsz)
+    spy = _LibraryGemms(monkeypatch)
+    trace = []
+    monkeypatch.setattr(_lib, "TRACE", trace)
+    with torch.no_grad():
+        out = m(x.to(DEV).bfloat16(), t.to(DEV).bfloat16(), None)
+    monkeypatch.setattr(_lib, "TRACE", None)
+    counts, gated = _trace_counts(trace)
+    lin = [(kern, P.m, P.n, P.k, bool(P.residual)) for fn, kern, P in trace if fn == "zigma_linear_fwd"]
+    in_proj = [l for l in lin if (l[2], l[3]) == (4 * E, E)]
+    out_proj = [l for l in lin if (l[2], l[3]) == (E, 2 * E)]
+    print(f"{name} B={Bsz}: in_proj {sorted(set(l[0] for l in in_proj))}, out_proj {sorted(set((l[0], l[4]) for l in out_proj))}, "
+          f"library {sorted(set(spy.calls))}, other {dict((k, v) for k, v in counts.items() if k[0] != 'zigma_linear_fwd')}")
+    assert spy.calls == [], spy.calls                                  # no library GEMM in the block loop
+    assert len(in_proj) == depth and len(out_proj) == depth, lin
+    assert all(l[0] == zr.kernel_name(zr.route("in_proj", tokens, 4 * E, E)) for l in in_proj), in_proj
+    assert all(l[0].startswith(("linear4w", "linear_ws", "linear_sm")) for l in in_proj + out_proj), lin
+    n_scan = sum(c for (fn, k), c in counts.items() if fn == "zigma_selective_scan_fwd" and k.startswith("scan_tok2"))
+    n_conv = sum(c for (fn, k), c in counts.items() if fn in ("zigma_conv_x_proj_fwd", "zigma_causal_conv1d_fwd"))
+    per = 2 if v2 else 1                                               # `v2`: two scans (and two conv / x_proj) per layer
+    assert n_scan == per * depth and n_conv == per * depth, counts
+    if Bsz == 64:        # 1536 workgroups: the six-resident form of the hot scan kernel, dt_proj + softplus inside
+        assert counts.get(("zigma_selective_scan_fwd", "scan_tok2_n16_dtproj_r6"), 0) == per * depth, counts
+        assert counts.get(("zigma_conv_x_proj_fwd", "conv_x_proj_mfma"), 0) == per * depth, counts
+    got = N(out)[[0, Bsz - 1]]
+    ref_noise = float(g["ref_bf16_vs_fp32"])
+    e_fp32, e_bf16 = rel_err(got, g["out"]), rel_err(got, g["out_bf16"])
+    print(f"{name} B={Bsz}: vs reference fp32 {e_fp32:.3e} (reference's own bf16: {ref_noise:.3e}), vs reference bf16 {e_bf16:.3e}")
+    assert np.isfinite(N(out)).all()
+    assert e_fp32 < 1.1 * ref_noise, (e_fp32, ref_noise)
+    assert e_bf16 < 1.5 * ref_noise, (e_bf16, ref_noise)
+
+
+def test_video_e768_serving_batch_block_path_vs_reference(monkeypatch):
+    """config 5's layer shapes (3d_zigzag8sst_b2.yaml: E = 768, 16 frames x 256 tokens) at B = 2 -> 8192 tokens: the reference sample
+    (r2_video_t16, B = 1) at batch position 0, noise at 1.  in_proj 768 -> 3072 runs as ONE launch of the generated 4-wave kernel, out_proj
+    1536 -> 768 on the few-token tiled kernel (128 x 192 tiles), x_proj on its split-K form; no library GEMM in the block loop; the
+    temporal layer takes the no-copy reset_period path."""
+    import zigma_amd.routing as zr
+    from zigma_amd import _lib
+    m, g, cfg, y1 = _r2_model("r2_video_t16", torch.bfloat16)
+    depth, E, Bsz = cfg["depth"], cfg["embed_dim"], 2
+    gen = torch.Generator().manual_seed(97)
+    x = torch.randn(Bsz, *g["x"].shape[1:], generator=gen)
+    t = torch.rand(Bsz, generator=gen)
+    y = torch.randint(0, cfg["num_classes"], (Bsz,), generator=gen)
+    x[0], t[0], y[0] = torch.from_numpy(g["x"][0]), float(g["t"][0]), int(g["y"][0])
+    spy = _LibraryGemms(monkeypatch)
+    trace = []
+    monkeypatch.setattr(_lib, "TRACE", trace)
+    with torch.no_grad():
+        out = m(x.to(DEV).bfloat16(), t.to(DEV).bfloat16(), y.to(DEV))
+    monkeypatch.setattr(_lib, "TRACE", None)
+    counts, gated = _trace_counts(trace)
+    c = lambda fn, k: counts.get((fn, k), 0)
+    print(f"video E=768 B=2: {counts}, library {spy.calls}")
+    assert spy.calls == [], spy.calls
+    assert zr.route("in_proj", 8192, 4 * E, E) == "tiled4w"
+    assert c("zigma_linear_fwd", "linear4w_256x256") == depth, counts                 # in_proj
+    assert c("zigma_linear_fwd", "linear_sm_128x192") == depth, counts                # out_proj
+    assert c("zigma_x_proj_fwd", "x_proj_splitk") == depth, counts
+    assert sum(v for (fn, k), v in counts.items() if fn == "zigma_selective_scan_fwd" and k.startswith("scan_tok2")) == depth, counts
+    resets = [P.reset_period for fn, _, P in trace if fn == "zigma_selective_scan_fwd"]
+    assert resets.count(cfg["video_frames"]) == 1, resets                              # s s t
+    ref_noise = float(g["ref_bf16_vs_fp32"])
+    e_fp32, e_bf16 = rel_err(N(out)[:1], g["out"]), rel_err(N(out)[:1], g["out_bf16"])
+    print(f"video E=768 B=2: vs reference fp32 {e_fp32:.3e} (reference's own bf16: {ref_noise:.3e}), vs reference bf16 {e_bf16:.3e}")
+    assert np.isfinite(N(out)).all() and e_fp32 < 1.1 * ref_noise and e_bf16 < 1.5 * ref_noise, (e_fp32, e_bf16, ref_noise)
 
 
 def test_no_text_block_path_trace_and_oracle(monkeypatch):

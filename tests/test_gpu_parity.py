@@ -979,15 +979,16 @@ def test_small_batch_sequence_split_matches_single_pass(Bsz, L):
 
 @pytest.mark.parametrize("M,K,N,bias,act", [(4096, 640, 2560, False, 1280), (2048, 1280, 640, False, None), (1040, 640, 512, False, None),
                                            (4096, 512, 640, True, None), (16, 64, 128, True, 64), (272, 128, 384, True, None),
-                                           (65536, 640, 2560, False, 1280)])
+                                           (65536, 640, 2560, False, 1280), (4096, 768, 3072, False, None), (65536, 768, 3072, False, 1536),
+                                           (2048, 1536, 768, False, None)])
 def test_linear_kernel_vs_float64(M, K, N, bias, act, monkeypatch):
     """zigma_linear_fwd (in_proj / out_proj / to_q / to_out on the matrix cores): every output against a float64 evaluation on
     the same bf16 operands (bias added before the single rounding; SiLU on columns >= act), token counts that are not
     multiples of the 256-token tile, and a strided (sliced) output."""
     from zigma_amd import _lib
-    import zigma_amd.linear as zl
+    import zigma_amd.routing as zr
     from zigma_amd.linear import linear, linear_eligible
-    monkeypatch.setattr(zl, "LINEAR_POLICY", "all")          # (the default policy leaves the 256-wide shapes to the library)
+    monkeypatch.setattr(zr, "POLICY", "all")          # (the default policy leaves the 256-wide shapes to the library)
     g = torch.Generator(device="cpu").manual_seed(M + N)
     x = torch.randn(M, K, generator=g).to(DEV, torch.bfloat16)
     w = (torch.randn(N, K, generator=g) * K ** -0.5).to(DEV, torch.bfloat16)
@@ -1008,20 +1009,21 @@ def test_linear_kernel_vs_float64(M, K, N, bias, act, monkeypatch):
         assert torch.equal(wide[:, 64:64 + N], y) and float(wide[:, :64].abs().max()) == 0 and float(wide[:, 64 + N:].abs().max()) == 0
 
 
-@pytest.mark.parametrize("M,K,N", [(65536, 640, 2560), (65536, 640, 512), (16384, 192, 4096), (65536, 1280, 256), (32768, 512, 1024)])
+@pytest.mark.parametrize("M,K,N", [(65536, 640, 2560), (65536, 640, 512), (16384, 192, 4096), (65536, 1280, 256), (32768, 512, 1024),
+                                   (65536, 768, 3072), (8192, 768, 3072), (16384, 768, 3072), (65536, 1536, 768), (65536, 768, 512)])      # E = 768: every shipped yaml
 def test_linear4w_kernel(M, K, N, monkeypatch):
     """The one-wave-per-SIMD projection kernel (csrc/linear4w.hip, generated main loop): served shapes report it, every output of
     sampled rows against float64 on the same bf16 operands, bit-identity with the 8-wave kernel (same MFMA, same accumulation
     order), run-to-run identity (a synchronisation bug shows as a flicker), and a strided output."""
     from zigma_amd import _lib
-    import zigma_amd.linear as zl
-    from zigma_amd.linear import linear, linear_eligible, routes_to_4w
+    import zigma_amd.routing as zr
+    from zigma_amd.linear import linear, linear_eligible
+    from zigma_amd.routing import serves_4w as routes_to_4w
     g = torch.Generator(device="cpu").manual_seed(M + N + K)
     x = torch.randn(M, K, generator=g).to(DEV, torch.bfloat16)
     w = (torch.randn(N, K, generator=g) * K ** -0.5).to(DEV, torch.bfloat16)
     assert routes_to_4w(M, N, K)
-    assert linear_eligible(x, w, None) == (N <= zl.AUTO_4W_MAX_N)       # default policy: where the kernel at least ties the library
-    monkeypatch.setattr(zl, "LINEAR_POLICY", "all")
+    monkeypatch.setattr(zr, "POLICY", "all")
     assert linear_eligible(x, w, None)
     y = linear(x, w)
     assert _lib.last_kernel() == "linear4w_256x256" and y.shape == (M, N)
@@ -1185,9 +1187,9 @@ def test_linear4w_narrow_tiles_and_gated_residual(Bsz, L, K, N, bias, res, monke
     sampled rows of every sample position class, against the 8-wave kernel (which rounds x W^T + b to bf16 before the gate: the two
     differ by that rounding only), run-to-run identity."""
     from zigma_amd import _lib
-    import zigma_amd.linear as zl
+    import zigma_amd.routing as zr
     from zigma_amd.linear import linear
-    monkeypatch.setattr(zl, "LINEAR_POLICY", "all")
+    monkeypatch.setattr(zr, "POLICY", "all")
     g = torch.Generator(device="cpu").manual_seed(Bsz + K + N)
     M = Bsz * L
     x = torch.randn(Bsz, L, K, generator=g).to(DEV, torch.bfloat16)
@@ -1217,10 +1219,10 @@ def test_linear4w_narrow_tiles_and_gated_residual(Bsz, L, K, N, bias, res, monke
 def test_linear_gated_residual_epilogue(Bsz, L, K, Nn, bias, monkeypatch):
     """out = residual + gate[b] * bf16(x @ W^T + bias) in the projection kernel's epilogue (the block's gated branch add) vs the
     same thing spelled out in float64 with the projection rounded to bf16 first."""
-    import zigma_amd.linear as zl
+    import zigma_amd.routing as zr
     from zigma_amd import _lib
     from zigma_amd.linear import gated_residual_eligible, linear
-    monkeypatch.setattr(zl, "LINEAR_POLICY", "all")
+    monkeypatch.setattr(zr, "POLICY", "all")
     g = torch.Generator(device="cpu").manual_seed(L + Nn)
     bf = torch.bfloat16
     x = torch.randn(Bsz, L, K, generator=g).to(DEV, bf)

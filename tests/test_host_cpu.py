@@ -83,19 +83,95 @@ def test_flag_constants_match_the_header():
 
 
 def test_knobs_env_override():
-    """ZIGMA_KNOBS: the one environment override of the module-level routing constants (A/B tools); unknown names raise"""
+    """ZIGMA_KNOBS: the one environment override of the module-level knobs (A/B tools); unknown names raise"""
     import subprocess
     import sys
-    code = ("import zigma_amd.mamba_simple as m, zigma_amd.model_zigma as z, zigma_amd.linear as l; "
-            "print(m.GATE_IN_IN_PROJ, m.OUT_PROJ_WS_MAX_TOKENS, z.TO_Q_WS_MAX_TOKENS, l.AUTO_4W_MAX_N)")
-    env = dict(os.environ, ZIGMA_KNOBS="mamba_simple.GATE_IN_IN_PROJ=True, mamba_simple.OUT_PROJ_WS_MAX_TOKENS=0,model_zigma.TO_Q_WS_MAX_TOKENS=16384,linear.AUTO_4W_MAX_N=512")
+    code = ("import zigma_amd.mamba_simple as m, zigma_amd.model_zigma as z, zigma_amd.routing as r; "
+            "print(m.GATE_IN_IN_PROJ, z.FUSE_OUT_PROJ_ADD, r.POLICY, r.route('in_proj', 65536, 2560, 640).row)")
+    env = dict(os.environ, ZIGMA_KNOBS="mamba_simple.GATE_IN_IN_PROJ=True, model_zigma.FUSE_OUT_PROJ_ADD=False,routing.DISABLED=in_proj.ws+to_q.sm")
     out = subprocess.run([sys.executable, "-c", code], cwd=ROOT, env=env, capture_output=True, text=True)
-    assert out.returncode == 0 and out.stdout.split() == ["True", "0", "16384", "512"], (out.stdout, out.stderr[-400:])
+    assert out.returncode == 0 and out.stdout.split() == ["True", "False", "auto", "in_proj.halves"], (out.stdout, out.stderr[-400:])
     out = subprocess.run([sys.executable, "-c", code], cwd=ROOT, env=dict(os.environ, ZIGMA_KNOBS=""), capture_output=True, text=True)
-    assert out.stdout.split() == ["False", "32768", "8192", "1024"], out.stdout
+    assert out.stdout.split() == ["False", "True", "auto", "in_proj.ws"], out.stdout
     bad = subprocess.run([sys.executable, "-c", "import zigma_amd.mamba_simple"], cwd=ROOT, env=dict(os.environ, ZIGMA_KNOBS="mamba_simple.NO_SUCH=1"),
                          capture_output=True, text=True)
     assert bad.returncode != 0 and "no knob" in bad.stderr
+
+
+def test_no_routing_environment_switches():
+    """the product path reads no per-feature environment variable for its routing: ZIGMA_KNOBS (tools), ZIGMA_AMD_LIB (A/B
+    builds) and HIPCC (the build) are the only ones besides torch.distributed's rendezvous variables"""
+    allowed = {"ZIGMA_KNOBS", "ZIGMA_AMD_LIB", "HIPCC", "RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "L4W_STORE_NT", "L4W_RES_AHEAD"}
+    seen = set()
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "zigma_amd")):
+        for f in files:
+            if f.endswith(".py"):
+                src = open(os.path.join(dirpath, f)).read()
+                seen |= set(re.findall(r"environ(?:\.get|\.setdefault)?\(?\[?\s*[\"']([A-Z0-9_]+)[\"']", src))
+    assert seen <= allowed, seen - allowed
+
+
+# The cells of the sweep below that run on the LIBRARY (F.linear = hipBLASLt), reviewed one by one (VERDICT r5 next 6 (ii)).  Everything else of
+# E x tokens x role runs on an own kernel.  Why each group is here:
+#   in_proj, every E, 4096 tokens           below 8192 tokens the library ties or beats every own form (tools/linear_ws_probe.py: a tie at 4096)
+#   in_proj, E = 1024, 8192 tokens          k = 1024 is not a weight-stationary width and 32 x 16 tiles... 8192 / 256 x 16 = 512 tiles: see below (NOT library)
+#   out_proj, E = 512 / 1024, 16 384 tokens  k = 1024 / 2048 are not 128-feature-panel widths; E = 512: 64 x 2 = 128 tiles is below the 4-wave kernel's floor
+ROUTING_LIBRARY_CELLS = {
+    ("in_proj", 512, 4096), ("in_proj", 640, 4096), ("in_proj", 768, 4096), ("in_proj", 1024, 4096),
+    ("out_proj", 512, 16384),
+}
+
+
+def test_routing_table():
+    """zigma_amd/routing.py: ONE table decides which kernel serves which projection.  Sweep E x tokens x role: (i) a row is chosen, deterministically,
+    and its kernel's shape limits hold; (ii) the cells that fall to the library are exactly the reviewed list above; (iii) the shipped shapes land on the
+    rows the profiles were taken with; (iv) the knobs (POLICY, DISABLED) do what they say."""
+    import zigma_amd.routing as zr
+    lib_cells = set()
+    for E in (512, 640, 768, 1024):
+        shapes = {"in_proj": (4 * E, E), "out_proj": (E, 2 * E), "to_q": (512, E), "to_out": (E, 512)}
+        for tokens in (4096, 8192, 16384, 32768, 65536, 131072):
+            for role, (n, k) in shapes.items():
+                r = zr.route(role, tokens, n, k)
+                assert r == zr.route(role, tokens, n, k) and r.kernel in zr.KERNELS and r.row.startswith(role + ".")
+                assert zr._SERVES[r.kernel](tokens, n, k), (role, E, tokens, r)
+                if r.kernel == "library":
+                    lib_cells.add((role, E, tokens))
+    assert lib_cells == ROUTING_LIBRARY_CELLS, (lib_cells - ROUTING_LIBRARY_CELLS, ROUTING_LIBRARY_CELLS - lib_cells)
+    # (iii) the README model at B = 64 and the shipped yamls' E = 768 at B = 64 / 8
+    assert zr.route("in_proj", 65536, 2560, 640).row == "in_proj.ws" and zr.route("in_proj", 65536, 3072, 768).row == "in_proj.tiled_wide_k"
+    assert zr.route("out_proj", 65536, 640, 1280) == zr.Route("tiled", True, "out_proj.tiled") and zr.route("out_proj", 16384, 640, 1280).row == "out_proj.ws128"
+    assert zr.route("out_proj", 8192, 768, 1536).row == "out_proj.sm" and zr.route("to_q", 8192, 512, 640).row == "to_q.sm"
+    assert zr.route("to_out", 65536, 640, 512) == zr.Route("tiled", True, "to_out.tiled") and zr.route("to_q", 65536, 512, 640).row == "to_q.tiled"
+    assert zr.kernel_name(zr.route("in_proj", 65536, 3072, 768), 65536, 3072, 768) == "linear4w_256x256"
+    assert zr.kernel_name(zr.route("to_q", 16384, 512, 640), 16384, 512, 640) == "linear_tn_"
+    # ADVICE r5 (medium): the 128-feature-panel form holds at most 32 panels — in_proj of an E = 1280 / 1536 model must not be claimed for it
+    assert not zr.serves_ws(16384, 5120, 1280) and not zr.serves_ws(16384, 6144, 1536) and zr.serves_ws(16384, 4096, 1280)
+    assert zr.route("in_proj", 16384, 5120, 1280).kernel == "tiled" and zr.route("in_proj", 16384, 6144, 1536).kernel == "tiled"
+    # (iv) knobs
+    try:
+        zr.DISABLED = {"in_proj.ws"}
+        assert zr.route("in_proj", 32768, 2560, 640).row == "in_proj.halves" and zr.route("in_proj", 16384, 2560, 640).row == "in_proj.library"
+        zr.DISABLED = "out_proj.tiled+out_proj.ws128"
+        assert zr.route("out_proj", 65536, 640, 1280).row == "out_proj.library"
+        zr.DISABLED, zr.POLICY = "", "off"
+        assert all(zr.route(role, 65536, n, k).kernel == "library" for role, n, k in (("in_proj", 2560, 640), ("to_out", 640, 512)))
+        zr.POLICY = "all"
+        assert zr.route("in_proj", 65536, 2560, 640) == zr.Route("tiled", False, "policy.all") and zr.route("out_proj", 16384, 640, 1280).fuse_add
+    finally:
+        zr.DISABLED, zr.POLICY = "", "auto"
+    with pytest.raises(ValueError):
+        zr.route("x_proj", 1, 1, 1)
+
+
+def test_project_on_cpu_falls_to_the_reference_composition():
+    """linear.project on tensors the own kernels cannot take (CPU, fp32) is F.linear (+ the gated add), never an own kernel and never an error"""
+    from zigma_amd.linear import project
+    g = torch.Generator().manual_seed(3)
+    x, w, b = torch.randn(2, 256, 64, generator=g), torch.randn(128, 64, generator=g), torch.randn(128, generator=g)
+    res, gate = torch.randn(2, 256, 128, generator=g), torch.randn(2, 128, generator=g)
+    assert torch.equal(project("in_proj", x, w), torch.nn.functional.linear(x, w))
+    assert torch.allclose(project("to_out", x, w, b, residual=res, gate=gate), res + gate[:, None] * torch.nn.functional.linear(x, w, b), atol=1e-5)
 
 
 def test_linear_ws_policy_limits_on_cpu_tensors():
@@ -331,16 +407,35 @@ def test_video16_no_copy_temporal_path_host_logic(monkeypatch):
     assert rel_err(out.numpy(), g["out"]) < 2e-5, rel_err(out.numpy(), g["out"])
 
 
-def test_oracle_model_vs_r2_reference_goldens():
-    """the numpy oracle against the round-2 reference outputs (16-frame video model; param_fill weights)."""
+@pytest.mark.parametrize("name", ["r2_small_video16", "r6_zigzag8_e768", "r6_sweep2_e768"])
+def test_oracle_model_vs_r2_reference_goldens(name):
+    """the numpy oracle against the round-2 / round-6 reference outputs (16-frame video model; the shipped yamls' E = 768 layer shapes with
+    zigzagN8 and with the bidirectional `v2`; param_fill weights)."""
     from oracle.param_fill import fill_state
     from zigma_amd.model_zigma import ZigMa
-    g = load_golden("r2_small_video16.npz")
+    g = load_golden(name + ".npz")
     cfg = ast.literal_eval(str(g["cfg"]))
     m = fill_state(ZigMa(device="cpu", **cfg), int(g["seed"]))
     om = zo.ZigMaOracle({k: v.numpy() for k, v in m.state_dict().items()}, cfg)
-    out = om.forward(g["x"], g["t"], g["y"])
+    out = om.forward(g["x"], g["t"], g.get("y"))
     assert rel_err(out, g["out"]) < 2e-5, rel_err(out, g["out"])
+
+
+@pytest.mark.parametrize("name", ["r6_zigzag8_e768", "r6_sweep2_e768"])
+def test_e768_host_logic_vs_reference(name, monkeypatch):
+    """Host logic of the E = 768 models (every shipped yaml: config/model/zigzag8_b1_pe2.yaml, sweep2_b1_pe2.yaml) with oracle-backed kernel
+    stand-ins against the REFERENCE's fp32 output: row tables of zigzagN8, the reversed table + second parameter set of `v2`
+    (mamba_simple.py:304-339)."""
+    import kernel_standins
+    from oracle.param_fill import fill_state
+    from zigma_amd.model_zigma import ZigMa
+    kernel_standins.install(monkeypatch)
+    g = load_golden(name + ".npz")
+    cfg = ast.literal_eval(str(g["cfg"]))
+    m = fill_state(ZigMa(device="cpu", **cfg), int(g["seed"])).eval()
+    with torch.no_grad():
+        out = m(torch.from_numpy(g["x"]), torch.from_numpy(g["t"]), None)
+    assert rel_err(out.numpy(), g["out"]) < 2e-5, rel_err(out.numpy(), g["out"])
 
 
 def test_postprocess_matches_reference_formulas():

@@ -4,7 +4,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from zigma_amd import _lib
 import zigma_amd.linear as zl
 from zigma_amd.linear import linear
-zl.LINEAR_POLICY = "all"
+# (linear() carries no policy: routing lives in zigma_amd/routing.py)
 F = torch.nn.functional
 dev, dt = "cuda", torch.bfloat16
 B, L = int(os.environ.get("B", 64)), 1024

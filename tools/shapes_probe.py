@@ -12,7 +12,7 @@ from zigma_amd.linear import linear, linear_eligible, linear_sm_eligible, linear
 from zigma_amd.selective_scan_interface import x_proj
 F = torch.nn.functional
 dev, dt = "cuda", torch.bfloat16
-zl.LINEAR_POLICY = "all"
+# (linear() carries no policy: routing lives in zigma_amd/routing.py)
 torch.manual_seed(0)
 out = open(os.path.join(ROOT, "gpurun_out", "r05_shapes_probe.jsonl"), "w")
 
@@ -43,7 +43,7 @@ for name, M, K, N in shapes:
     w = (torch.randn(N, K, device=dev) * K ** -0.5).to(dt)
     fs = {"lib": lambda: F.linear(x, w)}
     kern = {}
-    if linear_eligible(x, w, None, prefer_own=True):
+    if linear_eligible(x, w, None):
         fs["own"] = lambda: linear(x, w)
         linear(x, w); kern["own"] = _lib.last_kernel()
         fs["own_8w"] = lambda: linear(x, w, _probe_flags=0x2000)

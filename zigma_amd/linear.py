@@ -5,42 +5,14 @@ check runs with autograd off); linear_eligible itself refuses tensors that requi
 import torch
 
 from . import _lib
-
-import os
-
-# Which projections run on zigma_linear_fwd.  Measured at the headline shapes (M = 65 536 tokens), own 4-wave kernel (csrc/linear4w.hip)
-# vs hipBLASLt in us (profiles/r03_e_linear4w_probe.jsonl, r03_n_linear4w_epilogue_probe.jsonl; in the forward r03_t_bench_kernel_stats.csv):
-#   out_proj + gated add 122 vs 116 + the add in the norm kernel;  to_out + bias + gated add 54 (67 in the forward) vs 70;
-#   to_q 46-47 vs 44-47 (a tie);  the whole in_proj (N = 2560) 222 vs 200 as ONE launch, 2 x 104-105 as two half-width launches
-#   (N = 1280 each; mamba_simple.IN_PROJ_SPLIT, round 4 — the default, +1.8 % on the forward against the library).
-#   Round 4, in_proj as ONE launch again: the weight-stationary kernel (csrc/linear_ws.hip; mamba_simple.IN_PROJ_WS) 184-196 us.
-#   "auto" (default): every projection of the inference path the own kernel serves at least as fast as the library (to_q, to_out,
-#   out_proj with the block's gated add) — plus the in_proj halves, which the caller requests with prefer_own;
-#   "all": every eligible projection;  "off": library only.
-LINEAR_POLICY = os.environ.get("ZIGMA_LINEAR", "auto")
+from . import routing
 
 
-def routes_to_4w(m, n, k, bias=None):
-    """shapes zigma_linear_fwd serves with the one-wave-per-SIMD kernel (csrc/linear4w.hip): the wide epilogue-free projections"""
-    return bias is None and m % 256 == 0 and n % 128 == 0 and k % 64 == 0 and k >= 192 and (m // 256) * ((n + 255) // 256) >= 256
-
-
-FORCE_8W = os.environ.get("ZIGMA_LINEAR_8W", "0") == "1"      # A/B knob of tools/fwd_4w_ab.sh: pin the 8-wave kernel
-AUTO_4W_MAX_N = int(os.environ.get("ZIGMA_4W_MAX_N", "1024"))   # "auto": the 4-wave kernel where it at least ties the library (to_q; not in_proj)
-
-
-from . import _knobs  # noqa: E402
-_knobs.apply(globals(), "linear")
-
-
-def linear_eligible(x, weight, bias=None, fused_epilogue=False, prefer_own=False):
-    """policy (LINEAR_POLICY) + limits of zigma_linear_fwd: bf16, k % 64 == 0, n % 128 == 0, tokens % 8 == 0, aligned contiguous
-    rows, no autograd"""
-    if not (LINEAR_POLICY != "off" and x.is_cuda and x.dtype == torch.bfloat16 and weight.dtype == torch.bfloat16):
+def linear_eligible(x, weight, bias=None):
+    """LIMITS of zigma_linear_fwd's tiled kernels on these tensors (no policy — which projection runs where is zigma_amd/routing.py): bf16 on the
+    device, k % 64 == 0, n % 128 == 0, tokens % 8 == 0, aligned contiguous rows, no autograd"""
+    if not (x.is_cuda and x.dtype == torch.bfloat16 and weight.dtype == torch.bfloat16):
         return False
-    m_, (n_, k_) = x.numel() // max(x.shape[-1], 1), weight.shape
-    if LINEAR_POLICY == "auto" and bias is None and not fused_epilogue and not prefer_own and not (routes_to_4w(m_, n_, k_) and n_ <= AUTO_4W_MAX_N):
-        return False        # (auto: projections with an epilogue the library cannot fuse, and the wide ones the 4-wave kernel takes)
     if torch.is_grad_enabled() and (x.requires_grad or weight.requires_grad or (bias is not None and bias.requires_grad)):
         return False
     n, k = weight.shape
@@ -66,12 +38,11 @@ def linear_ws_eligible(x, weight, bias=None):
     bias; k = 512 or 640 with 256-feature panels (n % 256 == 0), or k = 1280 / 1536 with 128-feature panels (n % 128 == 0: the out_proj shapes, used
     below the tiled 4-wave kernel's floor); n <= 8192, tokens % 512 == 0 and enough of them for every workgroup of an XCD to own a tile, x rows a multiple
     of 128 elements apart — on top of linear_eligible's alignment rules."""
-    if bias is not None or not linear_eligible(x, weight, None, prefer_own=True):
+    if bias is not None or not linear_eligible(x, weight, None):
         return False
     n, k = weight.shape
-    m = x.numel() // k
-    pw = 256 if k in (512, 640) else 128 if k in (1280, 1536) else 0
-    return pw > 0 and n % pw == 0 and n <= 8192 and m % 512 == 0 and m // 512 >= 32 // (n // pw) and x.stride(-2) % 128 == 0
+    # (routing.serves_ws mirrors linear_ws_panel of the C side, including its 32-panel limit: n <= 4096 for the 128-feature form — ADVICE r5)
+    return routing.serves_ws(x.numel() // k, n, k) and x.stride(-2) % 128 == 0
 
 
 LINEAR_SM_FLAG = 0x8000          # zigma_linear_params_t.flags: ZIGMA_LINEAR_SM (csrc/linear_sm.hip)
@@ -82,7 +53,7 @@ def linear_sm_eligible(x, weight, bias=None):
     features are exactly 256 tiles): bf16, k % 64 == 0 and k >= 128, tokens % 128 == 0 (tiles of 160, 192 or 128 features), an optional bf16
     bias on an 8-byte boundary — on top of linear_eligible's alignment rules.  The gated residual epilogue: gated_residual_eligible, as for the
     tiled kernels."""
-    if not linear_eligible(x, weight, bias, fused_epilogue=True, prefer_own=True):
+    if not linear_eligible(x, weight, bias):
         return False
     if bias is not None and bias.data_ptr() % 8:
         return False
@@ -105,7 +76,7 @@ def linear(x, weight, bias=None, silu_from_col=None, out=None, _probe_flags=0, r
         out = torch.empty(x2.shape[0], n, device=x.device, dtype=x.dtype)
     o2 = out if out.dim() == 2 else out.view(-1, n)            # a view: the kernel writes through the row pitch
     P = _lib.LinearParams()
-    P.m, P.n, P.k, P.dtype, P.flags = x2.shape[0], n, k, _lib.dtype_id(x), int(_probe_flags) | (LINEAR_WS_FLAG if weight_stationary else LINEAR_SM_FLAG if few_tokens else (0x2000 if FORCE_8W else 0))
+    P.m, P.n, P.k, P.dtype, P.flags = x2.shape[0], n, k, _lib.dtype_id(x), int(_probe_flags) | (LINEAR_WS_FLAG if weight_stationary else LINEAR_SM_FLAG if few_tokens else 0)
     P.silu_from_col = n if silu_from_col is None else int(silu_from_col)
     P.x_row_stride, P.w_row_stride, P.out_row_stride = x2.stride(0), weight.stride(0), o2.stride(0)
     P.x, P.w, P.bias, P.out = _lib.ptr(x2), _lib.ptr(weight), _lib.ptr(bias), _lib.ptr(o2)
@@ -131,3 +102,42 @@ def gated_residual_eligible(x, residual, gate):
             and residual.stride(-1) == 1 and residual.stride(1) % 8 == 0 and residual.data_ptr() % 16 == 0
             and gate.dim() == 2 and gate.stride(1) == 1 and gate.stride(0) % 8 == 0 and gate.data_ptr() % 16 == 0
             and 256 * residual.stride(1) * 2 < 2 ** 31)
+
+
+def project(role, x, weight, bias=None, residual=None, gate=None):
+    """The block loop's projections through ONE dispatch (zigma_amd/routing.py): role in_proj | out_proj | to_q | to_out.
+    residual (B, L, n) + gate (B, n): the result is residual + gate[:, None] * (x @ weight.T + bias) — in the serving kernel's epilogue where the table says
+    so and the kernel's limits are met, as an addcmul behind the product otherwise.  Calls the own kernels cannot take (fp32 / fp16 models, CPU tensors,
+    autograd) go to wgrad.linear_train (F.linear; under autograd with the slab-wise weight gradient)."""
+    from .wgrad import linear_train
+    n, k = weight.shape
+    tokens = x.numel() // max(k, 1)
+    own = linear_eligible(x, weight, bias)
+    r = routing.route(role, tokens, n, k) if own else routing.Route("library", False, "not-bf16-inference")
+    kern = r.kernel
+    if own and kern != "library":
+        ok = {"ws": lambda: bias is None and linear_ws_eligible(x, weight), "ws128": lambda: bias is None and linear_ws_eligible(x, weight),
+              "sm": lambda: linear_sm_eligible(x, weight, bias), "tiled": lambda: True,
+              "tiled_halves": lambda: bias is None and x.dim() == 3 and linear_eligible(x, weight[:n // 2])}[kern]()
+        if not ok:
+            routing.REFUSED.append((role, tokens, n, k, kern))
+            kern = "library"
+    fuse = residual is not None and r.fuse_add and kern in ("sm", "tiled") and not torch.is_grad_enabled() and gated_residual_eligible(x, residual, gate)
+    if kern == "library":
+        y = linear_train(x, weight, bias)
+    elif kern == "tiled_halves":
+        y = torch.empty(*x.shape[:-1], n, device=x.device, dtype=x.dtype)
+        o2 = y.view(-1, n)
+        linear(x, weight[:n // 2], out=o2[:, :n // 2])
+        linear(x, weight[n // 2:], out=o2[:, n // 2:])
+    elif fuse:
+        return linear(x, weight, bias, residual=residual, gate=gate, few_tokens=kern == "sm")
+    else:
+        y = linear(x, weight, bias, weight_stationary=kern in ("ws", "ws128"), few_tokens=kern == "sm")
+    return y if residual is None else torch.addcmul(residual, gate.unsqueeze(1), y)
+
+
+def fuses_gated_add(role, tokens, n, k):
+    """will project(role, ...) carry the gated add in the projection's epilogue for this shape (bf16 inference)?"""
+    r = routing.route(role, tokens, n, k)
+    return r.fuse_add and r.kernel in ("sm", "tiled")

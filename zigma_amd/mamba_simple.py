@@ -9,45 +9,21 @@ row-index table consumed by the conv and scan kernels, so no `index_select`, `fl
 `rearrange(...).contiguous()` pass exists (reference :362-370, :320-337, :388-394).
 """
 import math
-import os
 
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
 from . import _knobs
-from . import linear as _zl
-from .linear import gated_residual_eligible, linear, linear_eligible, linear_sm_eligible, linear_ws_eligible, routes_to_4w
+from . import routing
+from .linear import fuses_gated_add, gated_residual_eligible, linear, linear_ws_eligible, project
 from .selective_scan_interface import mamba_inner_tok
-from .wgrad import linear_train
 
 NO_COPY_TEMPORAL = True      # video "t" layers on strided views (False: the transposing-copy form; A/B in the tests)
-
-
-IN_PROJ_SPLIT = os.environ.get("ZIGMA_IN_PROJ_SPLIT", "1") == "1"      # in_proj as two half-width launches of the own kernel
-IN_PROJ_SPLIT_MIN_TOKENS = 32768
-IN_PROJ_WS = os.environ.get("ZIGMA_IN_PROJ_WS", "1") == "1"            # in_proj on the weight-stationary kernel (csrc/linear_ws.hip) where it serves the shape
-# ... from 8192 tokens on: 33.5 us against 41.5 (library) / 37.1 (tiled kernel) there, 52 / 72 / 59 at 16 384, 93 / 106 / 106 at 32 768; a tie at 4096
-# (tools/linear_ws_probe.py with M=...)
-IN_PROJ_WS_MIN_TOKENS = 8192
-# in_proj of the wider models (k >= this: E = 768 of the reference's shipped yamls, config/model/zigzag8_b1_pe2.yaml:7-8) as ONE launch of the tiled kernel; 0: off
-IN_PROJ_ONE_LAUNCH_K = 704
+# Which kernel serves in_proj / out_proj at which size is zigma_amd/routing.py (ONE table, with the measurement behind every row).
 # the SiLU of the gate in in_proj's epilogue (linear_ws_kernel<.., SL>: z leaves as silu(z)) instead of in the scan's (ZIGMA_SCAN_Z_PREACTIVATED):
 # 20 of the scan's 311 VALU instructions per tile-wave move into the GEMM's MFMA gaps; the gate is then rounded to bf16 once more than in the
-# reference (selective_scan_fwd_kernel.cuh:293 applies silu in fp32 to the bf16 z).  Measured in round 5 (DESIGN.md §3.1): see there for the default.
-# out_proj (k = 1280 / 1536) on the weight-stationary kernel's 128-feature-panel form below the tiled 4-wave kernel's token floor (round 5)
-OUT_PROJ_WS_MAX_TOKENS = 32768
-# ... on the few-token tiled kernel (csrc/linear_sm.hip) where it serves the shape; the 128-feature-panel weight-stationary form otherwise
-OUT_PROJ_FEW_TOKENS = True
-# (stand-alone 18.9 / 34.8 us at 8192 / 16 384 tokens, E = 640, against 22.4 / 34.7 for the library and 25.3 / 38.1 for the 128-feature-panel form; in the
-# forward it pays up to 8192 tokens — ONE round of tiles: B = 8 4.64 against 4.81 ms under hipGraph — and loses at 16 384, two rounds of 144 KB workgroups:
-# 7.05 against 6.83 ms, profiles/r05_m_serving_latency_linear_sm.jsonl)
-OUT_PROJ_FEW_MIN_TOKENS, OUT_PROJ_FEW_MAX_TOKENS = 2048, 8192
-# the gated add in the few-token kernel's epilogue, or (False, the default) its plain product + the add inside the next norm kernel: the epilogue's residual rows
-# come cold from HBM with nothing on the CU to hide them — config 5 4.42-4.45 ms unfused against 4.53-4.55 fused under hipGraph, B = 8 a tie (4.78-4.81 both),
-# B = 16 +4 % fused (profiles/r05_p_few_token_fuse_ab.jsonl)
-OUT_PROJ_FEW_FUSE = False
-OUT_PROJ_FUSE_NEEDS_4W = True
+# reference (selective_scan_fwd_kernel.cuh:293 applies silu in fp32 to the bf16 z).  Measured in round 5 (DESIGN.md §3.1): a tie in the forward — off.
 GATE_IN_IN_PROJ = False
 _knobs.apply(globals(), "mamba_simple")      # ZIGMA_KNOBS="mamba_simple.GATE_IN_IN_PROJ=True,..." (A/B tools)
 
@@ -177,34 +153,19 @@ class Mamba(nn.Module):
 
     def forward(self, hidden_states, inference_params=None, residual=None, gate=None):
         """residual (B, L, E) + gate (B, E): returns residual + gate[:, None] * mixer(hidden_states) — the block's gated branch add
-        (reference model_zigma.py:441-445), carried by out_proj's epilogue when the projection kernel's limits are met."""
+        (reference model_zigma.py:441-445), carried by out_proj's epilogue where the routing table says so (linear.project)."""
         y = self._mamba_inner_forward(hidden_states, inference_params)
-        lin = self.out_proj
-        if residual is None:
-            return self._proj(y, lin)
-        if (not torch.is_grad_enabled() and linear_eligible(y, lin.weight, lin.bias, fused_epilogue=True)
-                and gated_residual_eligible(y, residual, gate)):
-            # (below the 4-wave kernel's token floor: the few-token tiled kernel carries the same epilogue)
-            return linear(y, lin.weight, lin.bias, residual=residual, gate=gate, few_tokens=self._few_tokens(y, lin))
-        return torch.addcmul(residual, gate.unsqueeze(1), self._proj(y, lin))
-
-    @staticmethod
-    def _few_tokens(y, lin):
-        tokens = y.shape[:-1].numel()
-        return bool(OUT_PROJ_FEW_TOKENS and OUT_PROJ_FEW_MIN_TOKENS <= tokens <= OUT_PROJ_FEW_MAX_TOKENS and linear_sm_eligible(y, lin.weight, lin.bias))
+        return project("out_proj", y, self.out_proj.weight, self.out_proj.bias, residual=residual, gate=gate)
 
     def out_add_fusable(self, residual, gate):
-        """True when forward(..., residual=, gate=) will carry the gated add in out_proj's epilogue (no-grad, bf16, 256-row samples)"""
+        """True when forward(..., residual=, gate=) will carry the gated add in out_proj's epilogue (no-grad, bf16, 256-row samples, and a row of the
+        routing table that fuses at this size)"""
         lin = self.out_proj
         if torch.is_grad_enabled() or not residual.is_cuda or residual.dtype != torch.bfloat16 or residual.dim() != 3:
             return False
         y = torch.empty(residual.shape[0], residual.shape[1], self.d_inner, device="meta", dtype=residual.dtype)   # shape / dtype stand-in
-        # (round 5: only where the 4-wave kernel takes the product — below its 256-tile floor the fused call runs on the 8-wave kernel, 48 us at
-        # 16 384 tokens against 34 for the library + the add inside the next norm kernel, profiles/r05_b_shapes_probe.jsonl)
         tokens = residual.shape[1] * residual.shape[0]
-        few = (OUT_PROJ_FEW_TOKENS and OUT_PROJ_FEW_FUSE and OUT_PROJ_FEW_MIN_TOKENS <= tokens <= OUT_PROJ_FEW_MAX_TOKENS and tokens % 128 == 0 and self.d_inner % 64 == 0
-               and self.d_inner >= 128)       # (the few-token tiled kernel carries the gated add too: end of round 5)
-        return ((few or (tokens >= 16384 and (routes_to_4w(tokens, lin.weight.shape[0], self.d_inner) or not OUT_PROJ_FUSE_NEEDS_4W or _zl.LINEAR_POLICY == "all")))
+        return (fuses_gated_add("out_proj", tokens, lin.weight.shape[0], self.d_inner)
                 and lin.weight.dtype == torch.bfloat16 and self.d_inner % 64 == 0
                 and lin.weight.shape[0] % 128 == 0 and gated_residual_eligible(y, residual, gate)
                 and (lin.bias is None or lin.bias.dtype == torch.bfloat16))
@@ -248,14 +209,15 @@ class Mamba(nn.Module):
         batch, seqlen, _ = hidden_states.shape
         A, Dp, dtb = self._scan_consts("")
         st = self.scan_type
-        zact = (GATE_IN_IN_PROJ and not torch.is_grad_enabled() and IN_PROJ_WS and self.in_proj.bias is None and hidden_states.is_cuda
+        zact = (GATE_IN_IN_PROJ and not torch.is_grad_enabled() and self.in_proj.bias is None and hidden_states.is_cuda
                 and hidden_states.dtype == torch.bfloat16 and (st == "v1" or st.startswith(("zigzagN", "hilbertN", "randomN")))
-                and self.d_state == 16 and seqlen % 16 == 0 and self.d_inner % 128 == 0 and batch * seqlen >= IN_PROJ_WS_MIN_TOKENS
-                and batch <= 65535 and linear_ws_eligible(hidden_states, self.in_proj.weight))
+                and self.d_state == 16 and seqlen % 16 == 0 and self.d_inner % 128 == 0 and batch <= 65535
+                and routing.route("in_proj", batch * seqlen, 2 * self.d_inner, hidden_states.shape[-1]).kernel == "ws"      # (256-feature panels only: the
+                and linear_ws_eligible(hidden_states, self.in_proj.weight))                                                  # narrow form has no SiLU epilogue)
         if zact:      # in_proj writes (x, silu(z)); the scan (hot kernel: 16-bit, 16 states, whole tiles) multiplies by the gate as it finds it
             xz = linear(hidden_states, self.in_proj.weight, weight_stationary=True, silu_from_col=self.d_inner)
         else:
-            xz = self._proj(hidden_states, self.in_proj)                              # (B, L, 2*Di) token-major
+            xz = project("in_proj", hidden_states, self.in_proj.weight, self.in_proj.bias)      # (B, L, 2*Di) token-major
         fwd = lambda t, perm: mamba_inner_tok(t, self.conv1d.weight, self.conv1d.bias, self.x_proj.weight,
                                                self.dt_proj.weight, A, Dp, dtb,
                                                perm=perm, out_rows=self._out_rows if perm is self._perm else None,
@@ -306,36 +268,3 @@ class Mamba(nn.Module):
         else:
             raise NotImplementedError
         return y                                                                    # (out_proj: forward())
-
-    @staticmethod
-    def _proj(x, lin):
-        """in_proj / out_proj: the hand-written MFMA kernel where it applies (zigma_amd.linear), the library otherwise"""
-        if linear_eligible(x, lin.weight, lin.bias):
-            return linear(x, lin.weight, lin.bias)
-        n = lin.weight.shape[0]
-        if (OUT_PROJ_FEW_TOKENS and lin.bias is None and lin.weight.shape[0] < lin.weight.shape[1] and OUT_PROJ_FEW_MIN_TOKENS <= x.shape[:-1].numel() <= OUT_PROJ_FEW_MAX_TOKENS
-                and linear_sm_eligible(x, lin.weight)):
-            # out_proj (n < k: d_inner -> E) at up to 8192 tokens: tiles of 128 tokens x n / 4 features, at most one per CU
-            return linear(x, lin.weight, few_tokens=True)
-        if (IN_PROJ_WS and lin.bias is None and x.shape[:-1].numel() >= IN_PROJ_WS_MIN_TOKENS and linear_ws_eligible(x, lin.weight)
-                and (lin.weight.shape[1] <= 640 or x.shape[:-1].numel() < OUT_PROJ_WS_MAX_TOKENS)):
-            # ONE launch, W_in panels resident in registers, only the tokens stream (half the L2 -> LDS bytes of the tiled kernel)
-            return linear(x, lin.weight, weight_stationary=True)
-        tokens = x.shape[:-1].numel()
-        if (IN_PROJ_ONE_LAUNCH_K and lin.bias is None and x.shape[-1] >= IN_PROJ_ONE_LAUNCH_K and n >= 2048 and tokens >= IN_PROJ_WS_MIN_TOKENS
-                and routes_to_4w(tokens, n, x.shape[-1]) and linear_eligible(x, lin.weight, None, prefer_own=True)):
-            # widths the weight-stationary kernel does not hold (E = 768: the panel would be 384 registers per lane): ONE launch of the 4-wave
-            # tiled kernel — 49 / 71 / 139 / 268 us at 8192 / 16 384 / 32 768 / 65 536 tokens against 60 / 72 / 137 / 263 (library) and
-            # 58 / 93 / 141 / 275 as two half-width launches (profiles/r05_b_shapes_probe.jsonl)
-            return linear(x, lin.weight)
-        if (IN_PROJ_SPLIT and lin.bias is None and n % 512 == 0 and n >= 2048 and x.dim() == 3
-                and linear_eligible(x, lin.weight[:n // 2], None, prefer_own=True) and x.shape[0] * x.shape[1] >= IN_PROJ_SPLIT_MIN_TOKENS):
-            # in_proj as TWO launches of the own 4-wave kernel, one per half of the output columns, into one (B, L, 2 d_inner) buffer:
-            # a half's weight panel (1.6 MB) stays in an XCD's L2 beside the activation panels, which the whole panel (3.3 MB) does
-            # not — 2 x ~100 us against 215-222 us for the same kernel on all 2560 columns and 190-200 us for hipBLASLt
-            out = torch.empty(*x.shape[:-1], n, device=x.device, dtype=x.dtype)
-            o2 = out.view(-1, n)
-            linear(x, lin.weight[:n // 2], out=o2[:, :n // 2])
-            linear(x, lin.weight[n // 2:], out=o2[:, n // 2:])
-            return out
-        return linear_train(x, lin.weight, lin.bias)       # (F.linear; under autograd with the slab-wise weight gradient, zigma_amd/wgrad.py)

@@ -32,7 +32,8 @@ from torch import Tensor
 from .attention import attention_math, cross_attn, cross_attn_eligible, cross_attn_train
 from . import embed as _embed
 from .layernorm import RMSNorm, block_norm, glue_bwd_eligible, layer_norm_fn, rms_norm_fn, scale_reduce_bwd
-from .linear import gated_residual_eligible, linear, linear_eligible, linear_sm_eligible, linear_ws_eligible
+from . import routing
+from .linear import linear, linear_eligible, project
 from .mamba_simple import Mamba
 from .wgrad import linear_train
 from .scan_paths import hilbert_path, reverse_permut_np, zigzag_path
@@ -124,35 +125,14 @@ class CrossAttention(nn.Module):
         self.to_v = nn.Linear(context_dim, inner_dim, bias=False)
         self.to_out = nn.Sequential(nn.Linear(inner_dim, query_dim), nn.Dropout(dropout))
 
-    @staticmethod
-    def _proj(x, lin):
-        # to_q at up to 8192 tokens on the few-token tiled kernel (csrc/linear_sm.hip: 128 tokens x 128 features
-        # per workgroup — 8192 tokens are exactly 256 tiles): 11.5 / 19.0 us at 8192 / 16 384 tokens against 19.8 / 20.2 for the library, 17.2 / 21.3
-        # for the weight-stationary kernel and 20.9 / 23.8 for the 8-wave kernel (profiles/r05_l_shapes_probe_linear_sm_128.jsonl)
-        no_grad = not (torch.is_grad_enabled() and (x.requires_grad or lin.weight.requires_grad))
-        if (TO_Q_FEW_TOKENS and lin.bias is None and no_grad and TO_Q_FEW_MIN_TOKENS <= x.shape[:-1].numel() <= TO_Q_FEW_MAX_TOKENS and linear_sm_eligible(x, lin.weight)):
-            return linear(x, lin.weight, few_tokens=True)
-        if (lin.bias is None and no_grad and (TO_Q_WS or x.shape[:-1].numel() <= TO_Q_WS_MAX_TOKENS) and linear_ws_eligible(x, lin.weight)):
-            return linear(x, lin.weight, weight_stationary=True)
-        if linear_eligible(x, lin.weight, lin.bias):
-            return linear(x, lin.weight, lin.bias)
-        # between the two (16 384 tokens: too few tiles for the 4-wave kernel, and the weight-stationary kernel slows the forward there): the
-        # 8-wave tiled kernel, 22.7-23.7 us against 20.9-21.9 for the library stand-alone — taken so that no library GEMM is left in the block
-        # loop at serving-size batches either (B = 16: 7.17 ms per forward with it against 7.16-7.35 at the end of round 4)
-        if (lin.bias is None and x.shape[:-1].numel() >= TO_Q_OWN_MIN_TOKENS and linear_eligible(x, lin.weight, None, prefer_own=True)):
-            return linear(x, lin.weight)
-        return linear_train(x, lin.weight, lin.bias)       # (F.linear; under autograd with the slab-wise weight gradient, zigma_amd/wgrad.py)
-
     def _proj_out(self, o, residual, gate):
         """to_out (+ dropout); with residual / gate the block's gated branch add `residual + gate * to_out(o)` (reference Block,
-        model_zigma.py:447-449) — in the projection kernel's epilogue when its limits are met"""
+        model_zigma.py:447-449) — in the projection kernel's epilogue where the routing table says so (zigma_amd/routing.py, role "to_out")"""
         lin = self.to_out[0]
-        if residual is None:
-            return self.to_out[1](self._proj(o, lin))
-        if not self.training and linear_eligible(o, lin.weight, lin.bias) and gated_residual_eligible(o, residual, gate):
-            few = TO_Q_FEW_TOKENS and TO_Q_FEW_MIN_TOKENS <= o.shape[:-1].numel() <= TO_Q_FEW_MAX_TOKENS and linear_sm_eligible(o, lin.weight, lin.bias)
-            return linear(o, lin.weight, lin.bias, residual=residual, gate=gate, few_tokens=bool(few))
-        return torch.addcmul(residual, gate.unsqueeze(1), self.to_out[1](self._proj(o, lin)))
+        if residual is None or self.training:
+            y = self.to_out[1](project("to_out", o, lin.weight, lin.bias))
+            return y if residual is None else torch.addcmul(residual, gate.unsqueeze(1), y)
+        return project("to_out", o, lin.weight, lin.bias, residual=residual, gate=gate)
 
     def forward(self, x, text, mask=None, kv=None, residual=None, gate=None):
         """kv: optional precomputed (to_k(text), to_v(text)), each (B, n_ctx, inner) — ZigMa.forward batches these
@@ -161,7 +141,7 @@ class CrossAttention(nn.Module):
         Bsz, L, _ = x.shape
         H = self.heads
         k, v = kv[:2] if kv is not None else (self.to_k(text), self.to_v(text))
-        q = self._proj(x, self.to_q)
+        q = project("to_q", x, self.to_q.weight, self.to_q.bias)
         if cross_attn_eligible(q, k, v, H):
             # HIP kernel: attention core in one pass (K/V of the head in LDS); under autograd its differentiable form (backward =
             # library GEMMs + ATen elementwise ops).  No fused SDPA anywhere: on ROCm that is an AOT-Triton kernel.
@@ -290,11 +270,8 @@ class Pending:
 # GEMM + the add inside the following norm kernel.  Per block (profiles/r02_b_bench_kernel_stats.csv vs r02_d_*): out_proj 127 -> 150 us,
 # pre-attention add + norm 68 -> 47, and with to_out's gated add: to_out 63 -> 78, pre-mixer add + norm 119 -> 102 — time moves from
 # the HBM-bound norm kernels into the projection epilogues, the forward is 0.1-0.3 % faster.
-TEXT_PROJ_OWN = os.environ.get("ZIGMA_TEXT_PROJ_OWN", "1") == "1"
-TO_Q_FEW_TOKENS, TO_Q_FEW_MIN_TOKENS, TO_Q_FEW_MAX_TOKENS = True, 2048, 8192      # (to_q and to_out; one round of tiles: see mamba_simple.OUT_PROJ_FEW_MAX_TOKENS)
-TO_Q_WS_MAX_TOKENS = 8192
-TO_Q_OWN_MIN_TOKENS = 8192
-TO_Q_WS = os.environ.get("ZIGMA_TO_Q_WS", "0") == "1"      # to_q on the weight-stationary kernel (A/B knob: a tie stand-alone)   # y_embedder and the batched K / V projection of all blocks (B x 77 text rows) on zigma_linear_fwd, rows padded to 256
+TEXT_PROJ_OWN = True      # (knob: ZIGMA_KNOBS="model_zigma.TEXT_PROJ_OWN=False")
+# y_embedder and the batched K / V projection of all blocks (B x 77 text rows) on zigma_linear_fwd, rows padded to 256
 
 
 def _padded_own_linear(x, weight, bias):
@@ -309,7 +286,7 @@ def _padded_own_linear(x, weight, bias):
     mp = -(-m // 256) * 256
     xp = x.new_zeros(mp, k)
     xp[:m] = x.reshape(m, k)
-    if not linear_eligible(xp, weight, bias, prefer_own=True):
+    if routing.POLICY == "off" or not linear_eligible(xp, weight, bias):
         return None
     return linear(xp, weight, bias)[:m].view(*x.shape[:-1], weight.shape[0])
 

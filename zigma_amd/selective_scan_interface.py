@@ -16,7 +16,6 @@ Backward (SURVEY.md §8f rank 1): `scan_bwd_tok` binds zigma_selective_scan_bwd;
 form of `mamba_inner_tok` (MambaInnerFn.backward, :367-434) that the blocks use when autograd is recording.  The
 (B, D, L)-layout entry points (`selective_scan_fn`, `mamba_inner_fn`) stay forward-only.
 """
-import os
 
 import torch
 import torch.nn.functional as F
@@ -251,7 +250,7 @@ def conv_x_proj(x_half, conv_w, conv_b, x_proj_weight, perm=None, _flags=0):
     return u, x_dbl
 
 
-DT_PROJ_IN_SCAN = os.environ.get("ZIGMA_DT_IN_SCAN", "1") == "1"     # dt_proj + softplus in the scan's tile prologue (MFMA) instead of a kernel of its own
+DT_PROJ_IN_SCAN = True     # dt_proj + softplus in the scan's tile prologue (MFMA) instead of a kernel of its own
 
 
 from . import _knobs  # noqa: E402

@@ -15,7 +15,7 @@ import torch.nn.functional as F
 SPLIT_WGRAD = True        # False: one GEMM (A/B in tools/train_probe.py)
 # forward projection and dX = dY W of the training path on the hand-written MFMA kernels (zigma_linear_fwd: weight-stationary / tiled) where they
 # serve the shape; dW stays the slab-wise batched product below.  "0": the library for both (A/B in tools/train_probe.py)
-OWN_TRAIN_GEMMS = os.environ.get("ZIGMA_TRAIN_OWN_GEMMS", "1") == "1"
+OWN_TRAIN_GEMMS = True
 
 
 def _bmm_takes_out_dtype():
@@ -37,17 +37,18 @@ def _own_linear(x, weight, bias=None, transposed=False):
     """x @ weight^T (+ bias) on zigma_linear_fwd if a kernel of it serves the call (autograd is off in here), else None.
     transposed: the product wanted is x @ weight (dX = dY W) — the transposed copy of the weight is only made once a kernel is known to
     take the call (eligibility is decided on shapes, dtypes and alignment, which the copy does not change)"""
+    from . import routing
     from .linear import linear, linear_eligible, linear_ws_eligible
-    if not OWN_TRAIN_GEMMS or not x.is_cuda or x.dtype != torch.bfloat16 or weight.dtype != torch.bfloat16:
+    if not OWN_TRAIN_GEMMS or routing.POLICY == "off" or not x.is_cuda or x.dtype != torch.bfloat16 or weight.dtype != torch.bfloat16:
         return None
     if transposed:
         wt = _ContiguousLike(weight)
-        if not ((bias is None and linear_ws_eligible(x, wt)) or linear_eligible(x, wt, bias, prefer_own=True)):
+        if not ((bias is None and linear_ws_eligible(x, wt)) or linear_eligible(x, wt, bias)):
             return None
         weight = weight.t().contiguous()
     if bias is None and linear_ws_eligible(x, weight):
         return linear(x, weight, weight_stationary=True)
-    if linear_eligible(x, weight, bias, prefer_own=True):
+    if linear_eligible(x, weight, bias):
         return linear(x, weight, bias)
     return None
 
