@@ -193,6 +193,70 @@ def check_against_unfused(model, x, t, y, out):
     return dict(finite=finite, rel_err_vs_unfused=err, bound=3e-2, checksum=float(out.double().sum()))
 
 
+def check_against_reference(model, wl, x, t, y):
+    """The driver line's REFERENCE distance.  AFTER the timed region the same model object gets the weights of the committed
+    reference run (tests/golden/r2_readme_b2.npz: the UNMODIFIED reference's ZigMa on CPU, fp32 and bf16, oracle/make_golden_r2.py; weights = the
+    deterministic fill both sides regenerate from the fixture's seed), the reference run's two samples replace batch positions 0 and B-1 of the TIMED
+    inputs, and one forward of the timed path — same batch size, same kernels, same routing — is compared with the reference's own outputs for those two
+    rows.  Bars as in tests/test_gpu_baseline_shapes.py: no further from the reference's fp32 result than 1.1 x the reference's own bf16 run is, and
+    within 1e-2 of the reference's bf16 result.  (The fill function lives under oracle/ as test infrastructure; it is a weight generator, not the
+    oracle, and runs here outside the timed region, as the checker only.)"""
+    import ast
+    import numpy as np
+    from oracle.param_fill import fill_state
+    path = os.path.join(ROOT, "tests", "golden", "r2_readme_b2.npz")
+    if not os.path.exists(path) or x.shape[0] < 2:
+        return None
+    g = np.load(path)
+    if ast.literal_eval(str(g["cfg"])) != wl["model"]:
+        return None
+    fill_state(model, int(g["seed"]))
+    x2, t2, y2 = x.clone(), t.clone(), y.clone()
+    for pos, src in ((0, 0), (x.shape[0] - 1, 1)):
+        x2[pos] = torch.from_numpy(g["x"][src]).to(x2)
+        t2[pos] = float(g["t"][src])
+        y2[pos] = torch.from_numpy(g["y"][src]).to(y2)
+    with torch.no_grad():
+        out = model(x2.bfloat16(), t2.bfloat16(), y2)[[0, x.shape[0] - 1]].float().cpu().numpy()
+    rel = lambda a, b: float(np.linalg.norm(a.astype(np.float64) - b) / np.linalg.norm(b))
+    noise = float(g["ref_bf16_vs_fp32"])
+    e32, e16 = rel(out, g["out"]), rel(out, g["out_bf16"])
+    ok = bool(np.isfinite(out).all() and e32 < 1.1 * noise and e16 < 1e-2)
+    if not ok:
+        raise SystemExit(f"bench.py: the timed path fails its reference check (vs reference fp32 {e32:.3e}, bar {1.1 * noise:.3e}; vs reference bf16 {e16:.3e}, bar 1e-2)")
+    return dict(rel_err_vs_reference_fp32=e32, bar_fp32=1.1 * noise, reference_own_bf16_vs_fp32=noise, rel_err_vs_reference_bf16=e16, bar_bf16=1e-2,
+                fixture="tests/golden/r2_readme_b2.npz (the unmodified reference on CPU; samples at batch positions 0 and B-1 of the timed inputs)", ok=ok)
+
+
+def box_calib(device):
+    """Two FIXED kernels (csrc/calib.hip) timed in this process after the timed region: a 1 GiB copy (GB/s, read + write) and the issue time of
+    v_fma_f32 / v_exp_f32 at the scan kernel's occupancy (ns per wave-instruction per SIMD).  Boxes of the pool differ by 3-4 %: with these
+    two numbers in the line a change of the headline between rounds can be told from a change of silicon."""
+    from zigma_amd import _lib
+    n = 1 << 30
+    src = torch.empty(n, device=device, dtype=torch.uint8).fill_(1)
+    dst = torch.empty(n, device=device, dtype=torch.uint8)
+    sink = torch.empty(1280 * 256, device=device, dtype=torch.float32)
+
+    def timed(mode, iters, reps):
+        P = _lib.CalibParams()
+        P.mode, P.iters = mode, iters
+        P.bytes, P.src, P.dst = (n, src.data_ptr(), dst.data_ptr()) if mode == 0 else (sink.numel() * 4, None, sink.data_ptr())
+        _lib.call("zigma_calib_launch", P, device)          # warm-up
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            _lib.call("zigma_calib_launch", P, device)
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) * 1e-3 / reps
+    t_copy = timed(0, 0, 10)
+    iters = 20000
+    t_fma, t_exp = timed(1, iters, 5), timed(2, iters, 5)
+    return dict(copy_1GiB_GBps=2 * n / t_copy / 1e9, v_fma_ns=t_fma / (iters * 16 * 5) * 1e9, v_exp_ns=t_exp / (iters * 8 * 5) * 1e9,
+                note="csrc/calib.hip: 1 GiB copy (read + write bytes / time); ns per wave-instruction per SIMD at 5 waves per SIMD, 1024 SIMDs busy")
+
+
 def _host_threads():
     try:
         return len(os.sched_getaffinity(0))
@@ -476,6 +540,11 @@ def main():
                                          f"B={batch}/GPU, bf16, one forward per step",
                                 global_batch=world * batch, seq_len=L, parallelism=f"batch-sharded x{world}"),
                     roofline=roof, check=check)
+        if not args.no_check:
+            line["box_calib"] = box_calib(device)
+            ref = check_against_reference(model, wl, x, t, y)        # (overwrites the model's weights: last use of the model)
+            if ref is not None:
+                line["check"] = dict(check or {}, **ref)
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(wl, args.workload)
         print(json.dumps(line), flush=True)

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define ZIGMA_ABI_VERSION 9   /* 2: parameter blocks grew (row tables in the backward, checkpoints, reset_period)
+#define ZIGMA_ABI_VERSION 10  /* 2: parameter blocks grew (row tables in the backward, checkpoints, reset_period)
                                * 3: scan block: `info` out-field, ZIGMA_SCAN_Z_PREACTIVATED flag; zigma_linear_fwd
                                * 4: zigma_linear_params_t grew (gated residual epilogue); zigma_conv_x_proj_fwd, zigma_q_attn_fwd
                                * 5: pruned — zigma_q_attn_fwd and the dt product of zigma_conv_xproj_params_t removed (measured no faster,
@@ -35,7 +35,8 @@ extern "C" {
                                * 6: zigma_cross_attn_bwd / zigma_cross_attn_bwd_chunks added
                                * 7: reset_period in the two backward blocks (zigma_scan_bwd_params_t reuses its padding, zigma_conv_bwd_params_t grew)
                                * 8: zigma_patch_embed_fwd, zigma_timestep_embed_fwd, zigma_final_layer_fwd, zigma_skinny_linear_fwd added
-                               * 9: zigma_scan_params_t grew: dt_x / dt_w (dt_proj + softplus inside the scan kernel) */
+                               * 9: zigma_scan_params_t grew: dt_x / dt_w (dt_proj + softplus inside the scan kernel)
+                               * 10: zigma_calib_launch (bench.py's box calibration) added; new ZIGMA_LINEAR_* kernel selectors of round 6 */
 
 /* zigma_scan_params_t.flags */
 #define ZIGMA_SCAN_Z_PREACTIVATED 2   /* z already holds silu(z) (the in_proj GEMM epilogue applied it): out_z = y * z */
@@ -584,6 +585,20 @@ int zigma_patch_embed_fwd(const zigma_patch_embed_params_t *p, void *stream);
 int zigma_timestep_embed_fwd(const zigma_timestep_embed_params_t *p, void *stream);
 int zigma_final_layer_fwd(const zigma_final_layer_params_t *p, void *stream);
 int zigma_skinny_linear_fwd(const zigma_skinny_params_t *p, void *stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Box calibration (bench.py `box_calib`; csrc/calib.hip).  NOT part of the drop-in surface: no reference interface maps to it.  Two fixed
+ * kernels whose times tell a slower box from slower code between rounds: mode 0 copies `bytes` (a multiple of 4096, 16-byte aligned
+ * pointers) from src to dst; mode 1 / 2 run `iters` x 16 v_fma_f32 / `iters` x 8 v_exp_f32 per wave on 1280 workgroups of 4 waves (5 waves
+ * per SIMD on 256 CUs) and write one float per thread to dst (`bytes` >= 1280 * 256 * 4 is the size of that buffer).
+ * ------------------------------------------------------------------------------------------ */
+typedef struct zigma_calib_params {
+    int32_t mode, iters;
+    int64_t bytes;
+    const void *src;
+    void *dst;
+} zigma_calib_params_t;
+int zigma_calib_launch(const zigma_calib_params_t *p, void *stream);
 
 /* ------------------------------------------------------------------------------------------ */
 const char *zigma_strerror(int status);

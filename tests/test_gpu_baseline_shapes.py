@@ -273,7 +273,9 @@ def test_e768_block_path_vs_reference(name, Bsz, monkeypatch):
           f"library {sorted(set(spy.calls))}, other {dict((k, v) for k, v in counts.items() if k[0] != 'zigma_linear_fwd')}")
     assert spy.calls == [], spy.calls                                  # no library GEMM in the block loop
     assert len(in_proj) == depth and len(out_proj) == depth, lin
-    assert all(l[0] == zr.kernel_name(zr.route("in_proj", tokens, 4 * E, E)) for l in in_proj), in_proj
+    assert all(l[0].startswith(zr.kernel_name(zr.route("in_proj", tokens, 4 * E, E), tokens, 4 * E, E)) for l in in_proj), in_proj
+    assert all(l[0].startswith(zr.kernel_name(zr.route("out_proj", tokens, E, 2 * E), tokens, E, 2 * E)) for l in out_proj), out_proj
+    assert zr.REFUSED == [], zr.REFUSED
     assert all(l[0].startswith(("linear4w", "linear_ws", "linear_sm")) for l in in_proj + out_proj), lin
     n_scan = sum(c for (fn, k), c in counts.items() if fn == "zigma_selective_scan_fwd" and k.startswith("scan_tok2"))
     n_conv = sum(c for (fn, k), c in counts.items() if fn in ("zigma_conv_x_proj_fwd", "zigma_causal_conv1d_fwd"))
@@ -315,7 +317,7 @@ def test_video_e768_serving_batch_block_path_vs_reference(monkeypatch):
     c = lambda fn, k: counts.get((fn, k), 0)
     print(f"video E=768 B=2: {counts}, library {spy.calls}")
     assert spy.calls == [], spy.calls
-    assert zr.route("in_proj", 8192, 4 * E, E) == "tiled4w"
+    assert zr.route("in_proj", 8192, 4 * E, E).row == "in_proj.tiled_wide_k" and zr.serves_4w(8192, 4 * E, E)
     assert c("zigma_linear_fwd", "linear4w_256x256") == depth, counts                 # in_proj
     assert c("zigma_linear_fwd", "linear_sm_128x192") == depth, counts                # out_proj
     assert c("zigma_x_proj_fwd", "x_proj_splitk") == depth, counts

@@ -33,7 +33,7 @@ def test_cabi_exports_every_declared_symbol(libpath):
         assert hasattr(L, name), name
     L.zigma_abi_version.restype = ctypes.c_int
     L.zigma_strerror.restype = ctypes.c_char_p
-    assert L.zigma_abi_version() == 9
+    assert L.zigma_abi_version() == 10
     assert L.zigma_strerror(-2) == b"size out of the supported range"
     from zigma_amd import _lib
     assert set(_lib.EXPORTS) <= declared
@@ -49,7 +49,7 @@ def test_ctypes_structs_match_the_header():
                "zigma_linear_params_t": _lib.LinearParams, "zigma_conv_xproj_params_t": _lib.ConvXProjParams,
                "zigma_glue_bwd_params_t": _lib.GlueBwdParams, "zigma_xattn_bwd_params_t": _lib.XAttnBwdParams, "zigma_patch_embed_params_t": _lib.PatchEmbedParams,
                "zigma_timestep_embed_params_t": _lib.TimestepEmbedParams, "zigma_final_layer_params_t": _lib.FinalLayerParams,
-               "zigma_skinny_params_t": _lib.SkinnyParams}
+               "zigma_skinny_params_t": _lib.SkinnyParams, "zigma_calib_params_t": _lib.CalibParams}
     lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "zigma_hip.h"', "int main(void){"]
     for cname, st in structs.items():
         lines.append(f'printf("{cname} %zu\\n", sizeof({cname}));')
@@ -79,7 +79,7 @@ def test_flag_constants_match_the_header():
     assert defs["ZIGMA_SCAN_KERNEL_TOK2"] == _lib.SCAN_KERNEL_TOK2
     assert defs["ZIGMA_SCAN_Z_PREACTIVATED"] == _lib.SCAN_Z_PREACTIVATED and defs["ZIGMA_SCAN_PROBE_V1"] == _lib.SCAN_PROBE_V1
     assert defs["ZIGMA_SCAN_PROBE_PRIO_SHIFT"] == _lib.SCAN_PROBE_PRIO_SHIFT and defs["ZIGMA_SCAN_PROBE_R5_SHIFT"] == _lib.SCAN_PROBE_R5_SHIFT
-    assert defs["ZIGMA_ABI_VERSION"] == 9
+    assert defs["ZIGMA_ABI_VERSION"] == 10
 
 
 def test_knobs_env_override():

@@ -146,6 +146,10 @@ class GlueBwdParams(C.Structure):
                 + [(n, vp) for n in ("dy", "a", "s", "out", "r1", "r2")])
 
 
+class CalibParams(C.Structure):
+    _fields_ = [("mode", i32), ("iters", i32), ("bytes", i64), ("src", vp), ("dst", vp)]
+
+
 class XProjParams(C.Structure):
     _fields_ = ([("m", i64), ("n", i32), ("k", i32), ("dtype", i32), ("flags", i32)]
                 + [(n, i64) for n in ("x_row_stride", "w_row_stride", "out_row_stride")] + [(n, vp) for n in ("x", "w", "out")])
@@ -168,7 +172,7 @@ EXPORTS = ("zigma_linear_fwd", "zigma_conv_x_proj_fwd", "zigma_scale_reduce_bwd"
            "zigma_causal_conv1d_bwd_workspace_bytes", "zigma_add_norm_bwd", "zigma_add_norm_bwd_workspace_bytes",
            "zigma_strerror",
            "zigma_cross_attn_bwd", "zigma_cross_attn_bwd_chunks", "zigma_patch_embed_fwd", "zigma_timestep_embed_fwd", "zigma_final_layer_fwd",
-           "zigma_skinny_linear_fwd", "zigma_abi_version", "zigma_last_kernel")
+           "zigma_skinny_linear_fwd", "zigma_calib_launch", "zigma_abi_version", "zigma_last_kernel")
 
 _lib = None
 
@@ -187,7 +191,7 @@ def lib():
                          ("zigma_selective_scan_bwd", ScanBwdParams), ("zigma_causal_conv1d_bwd", ConvBwdParams),
                          ("zigma_add_norm_bwd", NormBwdParams), ("zigma_cross_attn_fwd", XAttnParams), ("zigma_cross_attn_bwd", XAttnBwdParams), ("zigma_patch_embed_fwd", PatchEmbedParams),
                          ("zigma_timestep_embed_fwd", TimestepEmbedParams), ("zigma_final_layer_fwd", FinalLayerParams), ("zigma_skinny_linear_fwd", SkinnyParams), ("zigma_x_proj_fwd", XProjParams),
-                         ("zigma_linear_fwd", LinearParams), ("zigma_conv_x_proj_fwd", ConvXProjParams), ("zigma_scale_reduce_bwd", GlueBwdParams)):
+                         ("zigma_linear_fwd", LinearParams), ("zigma_conv_x_proj_fwd", ConvXProjParams), ("zigma_scale_reduce_bwd", GlueBwdParams), ("zigma_calib_launch", CalibParams)):
             fn = getattr(L, name)
             fn.argtypes = [C.POINTER(st), vp]
             fn.restype = C.c_int
@@ -203,7 +207,7 @@ def lib():
         L.zigma_strerror.restype = C.c_char_p
         L.zigma_abi_version.restype = C.c_int
         L.zigma_last_kernel.restype = C.c_char_p
-        if L.zigma_abi_version() != 9:
+        if L.zigma_abi_version() != 10:
             raise RuntimeError("zigma_amd: libzigma_hip.so ABI version mismatch")
         _lib = L
     return _lib

@@ -11,7 +11,7 @@ CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(HERE, "build")
 LIB = os.path.join(HERE, "lib", "libzigma_hip.so")
 SOURCES = ["api.hip", "selective_scan.hip", "scan_tok_bf16.hip", "scan_tok_f16.hip", "scan_tok_f32.hip",
-           "causal_conv1d.hip", "add_norm.hip", "dt_proj.hip", "scan_bwd.hip", "conv_bwd.hip", "norm_bwd.hip", "cross_attn.hip", "cross_attn_bwd.hip", "x_proj.hip", "linear.hip", "linear4w.hip", "linear_ws.hip", "linear_sm.hip", "conv_x_proj.hip", "glue_bwd.hip", "embed.hip", "skinny_linear.hip"]
+           "causal_conv1d.hip", "add_norm.hip", "dt_proj.hip", "scan_bwd.hip", "conv_bwd.hip", "norm_bwd.hip", "cross_attn.hip", "cross_attn_bwd.hip", "x_proj.hip", "linear.hip", "linear4w.hip", "linear_ws.hip", "linear_sm.hip", "conv_x_proj.hip", "glue_bwd.hip", "embed.hip", "skinny_linear.hip", "calib.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=fast", "-fno-slp-vectorize",
          "-I" + os.path.join(ROOT, "include"), "-I" + CSRC]
