@@ -174,6 +174,25 @@ def test_project_on_cpu_falls_to_the_reference_composition():
     assert torch.allclose(project("to_out", x, w, b, residual=res, gate=gate), res + gate[:, None] * torch.nn.functional.linear(x, w, b), atol=1e-5)
 
 
+def test_build_refuses_a_spilling_scan_kernel():
+    """zigma_amd/build.py parses the resource-usage remarks of the scan TUs: an instantiation of scan_tok2_kernel with scratch memory or a spilled
+    register fails the build (its inline-asm d16_hi row loads are invisible to the register allocator — ADVICE r5)"""
+    from zigma_amd import build
+    ok = ("x.inc:69:1: remark: Function Name: _ZN5zigma16scan_tok2_kernelINS_4BF16ELb1EEEv [-Rpass-analysis=kernel-resource-usage]\n"
+          "x.inc:69:1: remark:     VGPRs: 89 [-Rpass-analysis=kernel-resource-usage]\n"
+          "x.inc:69:1: remark:     ScratchSize [bytes/lane]: 0 [-Rpass-analysis=kernel-resource-usage]\n"
+          "x.inc:69:1: remark:     VGPRs Spill: 0 [-Rpass-analysis=kernel-resource-usage]\n"
+          "x.inc:9:1: remark: Function Name: _ZN5zigma5otherEv [-Rpass-analysis=kernel-resource-usage]\n"
+          "x.inc:9:1: remark:     ScratchSize [bytes/lane]: 64 [-Rpass-analysis=kernel-resource-usage]\n")
+    assert build.check_no_scratch(ok, "x.hip") == 1
+    with pytest.raises(RuntimeError, match="must not spill"):
+        build.check_no_scratch(ok.replace("ScratchSize [bytes/lane]: 0", "ScratchSize [bytes/lane]: 16"), "x.hip")
+    with pytest.raises(RuntimeError, match="must not spill"):
+        build.check_no_scratch(ok.replace("VGPRs Spill: 0", "VGPRs Spill: 3"), "x.hip")
+    with pytest.raises(RuntimeError, match="no instantiation"):
+        build.check_no_scratch("", "x.hip")
+
+
 def test_linear_ws_policy_limits_on_cpu_tensors():
     """linear_ws_eligible never claims a CPU tensor or a shape outside the kernel's limits (the C side re-checks and refuses)"""
     from zigma_amd.linear import linear_ws_eligible

@@ -22,7 +22,31 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=f
 # (the same switch on conv_x_proj.hip and cross_attn_bwd.hip removes their AGPR moves too and changes nothing measurable: 17.21-17.28 vs
 # 17.23-17.26 ms per forward, 97.5-98.2 vs 96.8-98.0 ms per training step, tools/fwd_vgpr_mfma_ab.sh)
 _VGPR_MFMA = ["-mllvm", "-amdgpu-mfma-vgpr-form=1"]
-SOURCE_FLAGS = {"cross_attn.hip": _VGPR_MFMA}
+# scan_tok2_kernel loads its bf16 rows with inline-asm `buffer_load_short_d16_hi` (csrc/scan_tok2.inc): the compiler does not see those writes, so a spill or
+# a live-range split of the destination registers between the load and the tile's fence would silently lose a row.  The two TUs that instantiate
+# the kernel are compiled with the resource-usage remarks on, and the build FAILS if any instantiation uses scratch memory or spills a register.
+_RES = ["-Rpass-analysis=kernel-resource-usage"]
+SOURCE_FLAGS = {"cross_attn.hip": _VGPR_MFMA, "scan_tok_bf16.hip": _RES, "scan_tok_f16.hip": _RES}
+NO_SCRATCH_KERNELS = ("scan_tok2_kernel",)
+
+
+def check_no_scratch(remarks, src):
+    """parse -Rpass-analysis=kernel-resource-usage output: every NO_SCRATCH_KERNELS instantiation must report ScratchSize 0 and no spills"""
+    import re
+    bad, seen, name = [], 0, None
+    for ln in remarks.splitlines():
+        m = re.search(r"remark: Function Name: (\S+)", ln)
+        if m:
+            name = m.group(1) if any(k in m.group(1) for k in NO_SCRATCH_KERNELS) else None
+            seen += name is not None
+            continue
+        m = re.search(r"remark:\s+(ScratchSize \[bytes/lane\]|SGPRs Spill|VGPRs Spill): (\d+)", ln)
+        if m and name and int(m.group(2)) != 0:
+            bad.append((name, m.group(1), int(m.group(2))))
+    if bad or not seen:
+        raise RuntimeError(f"{src}: scan_tok2_kernel must not spill (inline-asm d16_hi row loads are invisible to the register allocator): "
+                           f"{bad if bad else 'no instantiation found in the remarks'}")
+    return seen
 
 
 def _digest(paths, extra=()):
@@ -71,7 +95,15 @@ def build(force=False, verbose=True, sources=None, lib=None, extra_flags=()):
 
     def compile_one(job):
         cmd, o_stamp, o_want = job
-        run(cmd)
+        if _RES[0] in cmd:
+            if verbose:
+                print(" ".join(cmd), flush=True)
+            r = subprocess.run(cmd, check=True, capture_output=True, text=True)
+            n = check_no_scratch(r.stderr, cmd[-3])
+            if verbose:
+                print(f"  {os.path.basename(cmd[-3])}: {n} scan_tok2_kernel instantiations, no scratch, no spills", flush=True)
+        else:
+            run(cmd)
         open(o_stamp, "w").write(o_want)
 
     with ThreadPoolExecutor(max_workers=min(8, max(1, len(jobs)))) as ex:
