@@ -40,6 +40,8 @@ extern "C" {
 
 /* zigma_scan_params_t.flags */
 #define ZIGMA_SCAN_Z_PREACTIVATED 2   /* z already holds silu(z) (the in_proj GEMM epilogue applied it): out_z = y * z */
+#define ZIGMA_SCAN_ACCUMULATE 4        /* out_z += y * silu(z) instead of out_z = ...: the second sweep of the bidirectional `v2` scan type
+                                       * (mamba_simple.py:335-339) adds itself to the first one's result; served with dt_x / dt_w only (ABI 10) */
 #define ZIGMA_SCAN_PROBE_V1 0x100     /* A/B probe (tools/scan_ab.py): pin the first-generation token-major kernel */
 #define ZIGMA_SCAN_PROBE_PRIO_SHIFT 9 /* A/B probe: bit 9 = scan_tok2_kernel WITHOUT its wave-priority rotation */
 #define ZIGMA_SCAN_PROBE_R5_SHIFT 10  /* A/B probe: bit 10 = never the six-resident-workgroups form of scan_tok2_kernel */

@@ -540,6 +540,46 @@ def test_scan_tok2_dt_proj_in_kernel_preactivated_gate(Bsz, L, Di, R):
     assert e_raw < 4e-3, e_raw
 
 
+@pytest.mark.parametrize("io", ["bf16", "f16"])
+@pytest.mark.parametrize("Bsz,L,Di,R,use_perm", [(3, 1024, 192, 40, True), (2, 256, 64, 48, False), (22, 64, 64 * 70, 48, True)])
+def test_scan_tok2_accumulating_form(Bsz, L, Di, R, use_perm, io, monkeypatch):
+    """ZIGMA_SCAN_ACCUMULATE (round 6): mamba_inner_tok(add_to=y0) — the second sweep of `v2` adding itself to the first one's result in the scan's
+    epilogue (reference mamba_simple.py:335-339: out + out_b.flip) — against y0 + mamba_inner_tok(...) evaluated in fp32 on the separate results, on the
+    five- and the six-resident form (22 x 70 = 1540 workgroups) of the kernel; the in-place fallback (knob off) gives the rounded-twice sum."""
+    import zigma_amd.selective_scan_interface as ssi
+    from zigma_amd import _lib
+    dtype = torch.bfloat16 if io == "bf16" else torch.float16
+    g = torch.Generator().manual_seed(Bsz * L + Di)
+    Nst = 16
+    xz = torch.randn(Bsz, L, 2 * Di, generator=g).to(DEV, dtype)
+    cw, cb = (0.4 * torch.randn(Di, 1, 4, generator=g)).to(DEV, dtype), (0.1 * torch.randn(Di, generator=g)).to(DEV, dtype)
+    xw = (Di ** -0.5 * torch.randn(R + 2 * Nst, Di, generator=g)).to(DEV, dtype)
+    dw = (R ** -0.5 * torch.randn(Di, R, generator=g)).to(DEV, dtype)
+    A = -torch.exp(torch.log(torch.arange(1, Nst + 1).float())[None].repeat(Di, 1) + 0.2 * torch.randn(Di, Nst, generator=g)).to(DEV)
+    D, db = (1 + 0.2 * torch.randn(Di, generator=g)).to(DEV), (torch.randn(Di, generator=g) - 3).to(DEV)
+    perm = torch.randperm(L, generator=g).to(DEV, torch.int32) if use_perm else None
+    y0 = torch.randn(Bsz, L, Di, generator=g).to(DEV, dtype)
+    with torch.no_grad():
+        y = ssi.mamba_inner_tok(xz, cw, cb, xw, dw, A, D, db, perm=perm)
+        k_plain = _lib.last_kernel()
+        acc = y0.clone()
+        got = ssi.mamba_inner_tok(xz, cw, cb, xw, dw, A, D, db, perm=perm, add_to=acc)
+        k_acc = _lib.last_kernel()
+        monkeypatch.setattr(ssi, "ACCUMULATE_IN_SCAN", False)
+        acc2 = y0.clone()
+        got2 = ssi.mamba_inner_tok(xz, cw, cb, xw, dw, A, D, db, perm=perm, add_to=acc2)
+    assert got is acc and got2 is acc2
+    assert k_plain.startswith("scan_tok2_n16_dtproj") and k_acc == k_plain + "_acc", (k_plain, k_acc)
+    assert ("_r6" in k_acc) == (Bsz * (Di // 64) > 1280)
+    ref = y0.float() + y.float()                       # y is the rounded result of the plain call: the accumulating form adds the UNROUNDED one
+    ulp = 2.0 ** (-8 if io == "bf16" else -11)
+    err = (got.float() - ref).abs()
+    bound = ulp * (ref.abs() + y.float().abs()) + 1e-6      # one rounding of the sum + the rounding y carried
+    assert bool((err <= bound).all()), float((err / bound).max())
+    assert torch.equal(got2, (y0 + y))                 # the fallback IS the reference's two-rounding sum
+    assert rel_err(N(got), N(got2)) < (4e-3 if io == "bf16" else 6e-4)
+
+
 def test_scan_dt_in_kernel_limits():
     """What the in-kernel dt_proj (zigma_scan_params_t.dt_x) refuses — the limits tok2_dtp_ok() states, each hit on its own: with dt_x
     set no other kernel serves the call, so the C side answers ZIGMA_ERR_UNSUPPORTED and the caller has to keep the dt_proj kernel."""

@@ -1,9 +1,9 @@
 #!/bin/bash
 # rocprofv3 kernel-trace summaries of BASELINE configs 3 (the shipped yaml model, E=768 depth 24), 4, 5 and of the serving-size batches
 # (bench.py --batch 8 / 16): one kernel_stats csv each -> gpurun_out/prof_<tag>/ ; prints the top kernels and the number of library GEMM rows.
-# usage: tools/prof_configs.sh [tags...]   (default: 3y 4 5 b8 b16)
+# usage: tools/prof_configs.sh [tags...]   (default: 3y v2 4 5 b8 b16)
 R=${GRAFT_REPO_ROOT:-$PWD}
-TAGS=${@:-3y 4 5 b8 b16}
+TAGS=${@:-3y v2 4 5 b8 b16}
 cd /tmp && export TMPDIR=/tmp
 for tag in $TAGS; do
   rm -rf $R/gpurun_out/prof_$tag
@@ -19,7 +19,7 @@ R, tag = sys.argv[1], sys.argv[2]
 f = glob.glob(f"{R}/gpurun_out/prof_{tag}/**/*kernel_stats.csv", recursive=True)
 if not f:
     print(tag, "no kernel_stats.csv"); sys.exit(0)
-shutil.copy(f[0], f"{R}/gpurun_out/r05_cfg_{tag}_kernel_stats.csv")
+shutil.copy(f[0], f"{R}/gpurun_out/r06_cfg_{tag}_kernel_stats.csv")
 rows = list(csv.DictReader(open(f[0])))
 tot = sum(float(r["TotalDurationNs"]) for r in rows)
 lib = [r for r in rows if r["Name"].startswith("Cijk_")]

@@ -2,6 +2,7 @@
    (for a kernel trace per config: tools/prof_configs.sh).
    config 3: CelebA-latent shape (4x32x32), zigzagN8, unconditional, 50-step fixed-grid Euler ODE sampling, B=64
    config 3y: the same sampling run on the model the reference's yaml ships (config/model/zigzag8_b1_pe2.yaml: E=768, depth 24)
+   config v2: the same sampling run on the reference's bidirectional yaml (config/model/sweep2_b1_pe2.yaml: E=768, depth 24, scan_type v2 — two scans per layer)
    config 4: FacesHQ1024-latent shape (4x128x128, patch 1 -> L=16384), E=640 depth=18, B=4: forward + scan roofline
    config 5: UCF101 video (16 frames, 4x32x32, patch 2), zzvideo_sst, E=768 depth=24, 101 classes, B=2: forward"""
 import json
@@ -27,14 +28,14 @@ def timed(fn, iters, warm=1):
     return (time.perf_counter() - t0) / iters, out
 
 
-def config3(dev, dt, E, depth, tag):
-    cfg = dict(in_channels=4, img_dim=32, embed_dim=E, depth=depth, patch_size=1, scan_type="zigzagN8", use_pe=2)
+def config3(dev, dt, E, depth, tag, scan_type="zigzagN8"):
+    cfg = dict(in_channels=4, img_dim=32, embed_dim=E, depth=depth, patch_size=1, scan_type=scan_type, use_pe=2)
     m = bench.build_model(cfg, dev, dt)
     fn = Sampler(create_transport("Linear", "velocity")).sample_ode(sampling_method="euler", num_steps=50)
     z = torch.randn(64, 4, 32, 32, device=dev)
     with torch.no_grad():
         sec, traj = timed(lambda: fn(z, m.forward), 1, warm=1)
-    print(json.dumps(dict(config=tag, what=f"50-step Euler ODE sampling (49 NFE), B=64, unconditional E={E} depth={depth} zigzagN8",
+    print(json.dumps(dict(config=tag, what=f"50-step Euler ODE sampling (49 NFE), B=64, unconditional E={E} depth={depth} {scan_type}",
                           s_per_batch=sec, samples_per_s=64 / sec, ms_per_nfe=sec / 49 * 1e3, tokens_per_s=64 * 1024 * 49 / sec,
                           finite=bool(torch.isfinite(traj[-1]).all()), out_shape=list(traj.shape))), flush=True)
 
@@ -42,7 +43,7 @@ def config3(dev, dt, E, depth, tag):
 def main():
     import argparse
     ap = argparse.ArgumentParser()
-    ap.add_argument("--only", default=None, choices=["3", "3y", "4", "5"])
+    ap.add_argument("--only", default=None, choices=["3", "3y", "v2", "4", "5"])
     only = ap.parse_args().only
     dev, dt = "cuda", torch.bfloat16
     timer = bench.ScanTimer()
@@ -52,6 +53,8 @@ def main():
         config3(dev, dt, 640, 18, 3)
     if only in (None, "3y"):      # the shipped yaml of BASELINE configs[2] (reference config/model/zigzag8_b1_pe2.yaml:7-8)
         config3(dev, dt, 768, 24, "3y")
+    if only in (None, "v2"):      # reference config/model/sweep2_b1_pe2.yaml:4-10
+        config3(dev, dt, 768, 24, "v2", scan_type="v2")
     if only in (None, "4"):
         config4(dev, dt, timer)
     if only in (None, "5"):

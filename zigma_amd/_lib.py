@@ -41,7 +41,7 @@ class ScanParams(C.Structure):
     )
 
 
-SCAN_Z_PREACTIVATED = 2                                   # zigma_scan_params_t.flags
+SCAN_Z_PREACTIVATED, SCAN_ACCUMULATE = 2, 4                # zigma_scan_params_t.flags
 SCAN_PROBE_V1, SCAN_PROBE_PRIO_SHIFT, SCAN_PROBE_R5_SHIFT = 0x100, 9, 10           # A/B probes (tools/scan_ab.py, tools/r05_scan_ab.py)
 SCAN_KERNEL_GENERIC, SCAN_KERNEL_TOK, SCAN_KERNEL_TOK2 = 1, 2, 3   # zigma_scan_params_t.info[0]
 

@@ -189,7 +189,7 @@ extern "C" int zigma_selective_scan_fwd(const zigma_scan_params_t *pp, void *str
 #else
     constexpr int kProbeBits = 0;
 #endif
-    if (p.flags & ~(ZIGMA_SCAN_Z_PREACTIVATED | ZIGMA_SCAN_PROBE_V1 | (1 << ZIGMA_SCAN_PROBE_PRIO_SHIFT) | (1 << ZIGMA_SCAN_PROBE_R5_SHIFT) | kProbeBits)) return ZIGMA_ERR_UNSUPPORTED;
+    if (p.flags & ~(ZIGMA_SCAN_Z_PREACTIVATED | ZIGMA_SCAN_ACCUMULATE | ZIGMA_SCAN_PROBE_V1 | (1 << ZIGMA_SCAN_PROBE_PRIO_SHIFT) | (1 << ZIGMA_SCAN_PROBE_R5_SHIFT) | kProbeBits)) return ZIGMA_ERR_UNSUPPORTED;
     if (p.batch == 0 || p.dim == 0 || p.seqlen == 0) return ZIGMA_OK;  // empty (pointers may be NULL): nothing to launch
     if (p.dt_x) {       // ABI 9: dt_proj inside the token-major hot kernel; `delta` is not read (the layout checks below see u's strides)
         if (!p.u || !p.dt_w || !p.A || !p.B || !p.C || !p.z || !p.out_z) return ZIGMA_ERR_NULL;
@@ -199,6 +199,7 @@ extern "C" int zigma_selective_scan_fwd(const zigma_scan_params_t *pp, void *str
         if ((p.io_dtype != ZIGMA_BF16 && p.io_dtype != ZIGMA_F16) || !tok_eligible(q) || p.batch > 65535) return ZIGMA_ERR_UNSUPPORTED;
         return p.io_dtype == ZIGMA_BF16 ? launch_scan_tok_bf16_dtp(q, stream) : launch_scan_tok_f16_dtp(q, stream);
     }
+    if (p.flags & ZIGMA_SCAN_ACCUMULATE) return ZIGMA_ERR_UNSUPPORTED;       // (only the in-kernel dt_proj form above adds to out_z)
     if (!p.u || !p.delta || !p.A || !p.B || !p.C) return ZIGMA_ERR_NULL;
     if (p.z && !p.out_z) return ZIGMA_ERR_NULL;
     if (!p.z && !p.out) return ZIGMA_ERR_NULL;

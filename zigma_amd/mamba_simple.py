@@ -227,10 +227,12 @@ class Mamba(nn.Module):
         elif st == "v2":
             A_b, Dp_b, dtb_b = self._scan_consts("_b")
             y = fwd(xz, None)
-            y_b = mamba_inner_tok(xz, self.conv1d_b.weight, self.conv1d_b.bias, self.x_proj_b.weight,
-                                  self.dt_proj_b.weight, A_b, Dp_b, dtb_b,
-                                  perm=self._reversed_table(seqlen, xz.device), delta_softplus=True)
-            y = y + y_b                                   # both already in token order
+            if torch.is_grad_enabled() and (xz.requires_grad or self.conv1d_b.weight.requires_grad):
+                y = y + mamba_inner_tok(xz, self.conv1d_b.weight, self.conv1d_b.bias, self.x_proj_b.weight, self.dt_proj_b.weight, A_b, Dp_b, dtb_b,
+                                        perm=self._reversed_table(seqlen, xz.device), delta_softplus=True)      # both already in token order
+            else:       # inference: the reversed sweep ADDS itself to y (in its scan's epilogue where the hot kernel serves the call) — no `out + out_b.flip` pass
+                y = mamba_inner_tok(xz, self.conv1d_b.weight, self.conv1d_b.bias, self.x_proj_b.weight, self.dt_proj_b.weight, A_b, Dp_b, dtb_b,
+                                    perm=self._reversed_table(seqlen, xz.device), delta_softplus=True, add_to=y)
         elif st.startswith(("zigzagN", "hilbertN", "randomN")):
             if self.extras:
                 raise NotImplementedError("extras > 0 is never produced by ZigMa (model_zigma.py:686)")

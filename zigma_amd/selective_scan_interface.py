@@ -65,14 +65,15 @@ def _as_bgnl(M, name):
 
 def scan_raw(u, delta, A, B, C, D=None, z=None, delta_bias=None, delta_softplus=False, *, out=None, out_z=None,
              x=None, z_row_index=None, out_row_index=None, want_out=True, checkpoints=None, reset_period=0,
-             chunk_len=2048, z_preactivated=False, info=None, _probe_flags=0, dt_x=None, dt_w=None):
+             chunk_len=2048, z_preactivated=False, info=None, _probe_flags=0, dt_x=None, dt_w=None, accumulate=False):
     """Launch zigma_selective_scan_fwd.  All tensors are logical (batch, dim, seqlen) VIEWS with arbitrary
     strides (token-major tensors come in as `.transpose(1, 2)`); B/C are (D, N) f32 or (B, G, N, L) views.
     Outputs that are None are allocated here with the reference's conventions (out like delta, out_z like z).
     z_preactivated: z already holds silu(z) (ZIGMA_SCAN_Z_PREACTIVATED; hot token-major kernel only).
     info: optional list; receives [kernel family (_lib.SCAN_KERNEL_*), 1 if `checkpoints` is being written].
     dt_x, dt_w (ABI 9, with delta=None): dt_proj + bias + softplus inside the token-major hot kernel — dt_x (batch, seqlen, >= dt_rank)
-    bf16 rows in SCAN order (x_dbl as x_proj wrote it), dt_w (dim, dt_rank); delta' = softplus(dt_x[..., :dt_rank] @ dt_w.T + delta_bias)."""
+    bf16 rows in SCAN order (x_dbl as x_proj wrote it), dt_w (dim, dt_rank); delta' = softplus(dt_x[..., :dt_rank] @ dt_w.T + delta_bias).
+    accumulate (with dt_x / dt_w only): out_z += y * silu(z) — the second sweep of `v2` adds itself to the first one's result (ZIGMA_SCAN_ACCUMULATE)."""
     dev = _lib.require_device(u, delta, A, B, C, D, z, delta_bias, out, out_z, x, z_row_index, out_row_index, dt_x, dt_w)
     if delta is None:
         if dt_x is None or dt_w is None or not delta_softplus:
@@ -98,7 +99,9 @@ def scan_raw(u, delta, A, B, C, D=None, z=None, delta_bias=None, delta_softplus=
     P.batch, P.dim, P.seqlen, P.dstate = batch, dim, L, N
     P.delta_softplus = int(bool(delta_softplus))
     P.io_dtype = _lib.dtype_id(u)
-    P.chunk_len, P.flags = int(chunk_len), (_lib.SCAN_Z_PREACTIVATED if z_preactivated else 0) | int(_probe_flags)
+    if accumulate and (dt_x is None or out_z is None):
+        raise RuntimeError("accumulate=True is served by the in-kernel dt_proj form only (dt_x / dt_w) and needs the out_z to add to")
+    P.chunk_len, P.flags = int(chunk_len), (_lib.SCAN_Z_PREACTIVATED if z_preactivated else 0) | (_lib.SCAN_ACCUMULATE if accumulate else 0) | int(_probe_flags)
     P.is_variable_B, P.is_variable_C = int(var_b), int(var_c)
     groups = 1
     bc_dt = None
@@ -250,6 +253,7 @@ def conv_x_proj(x_half, conv_w, conv_b, x_proj_weight, perm=None, _flags=0):
     return u, x_dbl
 
 
+ACCUMULATE_IN_SCAN = True     # `v2`: the second sweep's add in its scan epilogue (False: the in-place add; A/B in tests / tools)
 DT_PROJ_IN_SCAN = True     # dt_proj + softplus in the scan's tile prologue (MFMA) instead of a kernel of its own
 
 
@@ -541,7 +545,7 @@ def mamba_inner_fn_no_out_proj(xz, conv1d_weight, conv1d_bias, x_proj_weight, de
 
 def mamba_inner_tok(xz, conv1d_weight, conv1d_bias, x_proj_weight, delta_proj_weight, A, D, delta_bias, *,
                     perm=None, out_rows=None, B_proj_bias=None, C_proj_bias=None, delta_softplus=True, out=None,
-                    reset_period=0, z_preactivated=False):
+                    reset_period=0, z_preactivated=False, add_to=None):
     """Token-major Mamba inner (no out_proj).
 
     xz: (batch, seqlen, 2*d_inner), token order, channel contiguous (the in_proj GEMM output as is).
@@ -556,14 +560,17 @@ def mamba_inner_tok(xz, conv1d_weight, conv1d_bias, x_proj_weight, delta_proj_we
           conv window and SSM state restart there (the video temporal layers: batch = k, seqlen = b * t on strided views).
     z_preactivated: the z half of xz already holds silu(z) (an in_proj epilogue wrote it; inference, 16-bit, d_state 16,
           seqlen % 16 == 0 only — the hot kernel's ZIGMA_SCAN_Z_PREACTIVATED form).
+    add_to: optional (batch, seqlen, d_inner) tensor y0 in token order (inference only): the result is y0 + y, written INTO y0 and returned — the second
+          sweep of `v2` (mamba_simple.py:335-339).  Where the in-kernel dt_proj form of the scan serves the call the add rides in its epilogue
+          (ZIGMA_SCAN_ACCUMULATE: no elementwise pass); otherwise it is an in-place add behind the scan.
     Returns y (batch, seqlen, d_inner) in token order = out_z of the reference's scan, before out_proj.
     """
     if xz.dim() != 3 or xz.stride(2) != 1:
         raise RuntimeError("xz must be (batch, seqlen, 2*d_inner) with contiguous channels")
     if torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in (
             xz, conv1d_weight, conv1d_bias, x_proj_weight, delta_proj_weight, A, D, delta_bias)):
-        if B_proj_bias is not None or C_proj_bias is not None or not delta_softplus or out is not None or z_preactivated:
-            raise NotImplementedError("differentiable mamba_inner_tok: no B/C projection bias, softplus on, no out=, no pre-activated gate")
+        if B_proj_bias is not None or C_proj_bias is not None or not delta_softplus or out is not None or z_preactivated or add_to is not None:
+            raise NotImplementedError("differentiable mamba_inner_tok: no B/C projection bias, softplus on, no out= / add_to=, no pre-activated gate")
         return mamba_inner_tok_train(xz, conv1d_weight, conv1d_bias, x_proj_weight, delta_proj_weight, A, D, delta_bias,
                                      perm=perm, out_rows=out_rows, reset_period=reset_period)
     Bsz, L, C2 = xz.shape
@@ -584,17 +591,19 @@ def mamba_inner_tok(xz, conv1d_weight, conv1d_bias, x_proj_weight, delta_proj_we
         else:
             x_dbl = F.linear(u, x_proj_weight)                           # (B, L, R + 2N)   GEMM
     return _inner_tok_tail(u, x_dbl, z_half, delta_proj_weight, A, D, delta_bias, perm, out_rows, B_proj_bias, C_proj_bias,
-                           delta_softplus, out, reset_period, z_preactivated)
+                           delta_softplus, out, reset_period, z_preactivated, add_to)
 
 
 def _inner_tok_tail(u, x_dbl, z_half, delta_proj_weight, A, D, delta_bias, perm, out_rows, B_proj_bias, C_proj_bias,
-                    delta_softplus, out, reset_period, z_preactivated):
+                    delta_softplus, out, reset_period, z_preactivated, add_to=None):
     """dt_proj (+ softplus) and the scan over u (scan order), x_dbl, z (token order): the part of the inner function behind x_proj"""
     Bsz, L, Di = u.shape
     R = delta_proj_weight.shape[1]
     N = A.shape[1]
+    if add_to is not None and out is not None:
+        raise RuntimeError("mamba_inner_tok: pass out= or add_to=, not both")
     in_scan = (DT_PROJ_IN_SCAN and delta_softplus
-               and dt_in_scan_eligible(u, x_dbl, delta_proj_weight, reset_period, out, dstate=N, z=z_half)
+               and dt_in_scan_eligible(u, x_dbl, delta_proj_weight, reset_period, out if add_to is None else add_to, dstate=N, z=z_half)
                and B_proj_bias is None and C_proj_bias is None and not split_chunk_len(Bsz, Di, L, reset_period))
     if in_scan:                      # dt_proj + bias + softplus inside the scan kernel's tile prologue: delta is never materialised
         delta = None
@@ -608,7 +617,8 @@ def _inner_tok_tail(u, x_dbl, z_half, delta_proj_weight, A, D, delta_bias, perm,
         Bm = Bm + B_proj_bias.to(Bm.dtype)
     if C_proj_bias is not None:
         Cm = Cm + C_proj_bias.to(Cm.dtype)
-    y = out if out is not None else torch.empty(Bsz, L, Di, device=u.device, dtype=u.dtype)
+    acc = add_to is not None and in_scan and ACCUMULATE_IN_SCAN          # the scan's epilogue adds to add_to; else an in-place add behind it
+    y = add_to if acc else out if out is not None else torch.empty(Bsz, L, Di, device=u.device, dtype=u.dtype)
     # few workgroups (small batch, or long sequences of few samples): hand the kernel a carry buffer and a chunk length so
     # that it splits the sequence over ~768 workgroups (3 per CU): chunk-local states -> combine -> seeded second pass
     xc, chunk_len = None, split_chunk_len(Bsz, Di, L, reset_period)
@@ -620,5 +630,5 @@ def _inner_tok_tail(u, x_dbl, z_half, delta_proj_weight, A, D, delta_bias, perm,
              Cm.transpose(1, 2).unsqueeze(1), D, z_half.transpose(1, 2), delta_bias, delta_softplus,
              out_z=y.transpose(1, 2), z_row_index=perm, out_row_index=perm if out_rows is None else out_rows,
              want_out=False, x=xc, reset_period=reset_period, chunk_len=chunk_len, z_preactivated=z_preactivated,
-             dt_x=x_dbl if in_scan else None, dt_w=delta_proj_weight if in_scan else None)
-    return y
+             dt_x=x_dbl if in_scan else None, dt_w=delta_proj_weight if in_scan else None, accumulate=acc)
+    return y if (add_to is None or acc) else add_to.add_(y)
