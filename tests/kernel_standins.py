@@ -42,7 +42,7 @@ def scan_raw(u, delta, A, B, C, D=None, z=None, delta_bias=None, delta_softplus=
              x=None, z_row_index=None, out_row_index=None, want_out=True, checkpoints=None, reset_period=0,
              chunk_len=2048, z_preactivated=False, info=None, dt_x=None, dt_w=None, accumulate=False):
     assert checkpoints is None and not z_preactivated and not accumulate, "stand-in: GPU-only features"
-    if delta is None:                                 # ABI 9: dt_proj inside the scan; (B, L, >= R) rows x (D, R) -> (B, D, L)
+    if delta is None or dt_x is not None:             # ABI 9 / 10: dt_proj inside the scan (delta absent, or the split's workspace); (B, L, >= R) rows x (D, R) -> (B, D, L)
         delta = torch.einsum("blr,dr->bdl", dt_x[:, :, :dt_w.shape[1]].float(), dt_w.float()).to(u.dtype)
     if info is not None:
         info[:] = [2, 0]

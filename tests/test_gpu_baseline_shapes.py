@@ -146,8 +146,8 @@ def test_bench_block_path_vs_reference(variant, monkeypatch):
     from zigma_amd.selective_scan_interface import split_chunk_len
     if not split_chunk_len(Bsz, 2 * E, 1024):      # whole-sequence mode of the hot scan kernel: dt_proj + softplus inside it (round 4)
         assert dt_in_scan == depth and n_dt == 0, counts
-    else:                               # sequence-split mode (small batches): the dt_proj kernel of its own
-        assert dt_in_scan == 0 and n_dt == depth, counts
+    else:                               # sequence-split mode (small batches): dt_proj + softplus inside the split's FIRST pass (round 6), no kernel of its own
+        assert dt_in_scan == 0 and n_dt == 0 and counts.get(("zigma_selective_scan_fwd", "scan_tok2_n16_split_dtproj"), 0) == depth, counts
     n_ws = counts.get(("zigma_linear_fwd", "linear_ws"), 0)
     if variant == "gate_in_in_proj_b32":
         n_ws_silu = counts.get(("zigma_linear_fwd", "linear_ws_silu"), 0)
@@ -482,9 +482,19 @@ def test_config4_l16384_conv_scan_carries():
                  out_z=y.transpose(1, 2), z_row_index=p32, out_row_index=p32, want_out=False, x=xc, chunk_len=2048)
         assert _lib.last_kernel().startswith("scan_tok")
         y_inner = mamba_inner_tok(xzd, cw, cb, xw, dw, A, D, db, perm=p32, out_rows=p32)
-    # the op the model calls == the stages above (it splits into 1024-step chunks: the carries are combined in another
-    # association, fp32 rounding only)
-    assert rel_err(N(y_inner), N(y)) < 1e-4
+    # the op the model calls == the stages above: it splits into 1024-step chunks (the carries are combined in another association) and, since round 6, forms
+    # delta INSIDE the split's first pass (MFMA + softplus there, written rounded for the second pass) — the dt_proj kernel's softplus is another formula, so a
+    # few step sizes land on the neighbouring bf16 value
+    assert _lib.last_kernel() == "scan_tok2_n16_split_dtproj"
+    assert rel_err(N(y_inner), N(y)) < 1e-3
+    import zigma_amd.selective_scan_interface as ssi
+    ssi.DT_PROJ_IN_SPLIT = False
+    try:
+        with torch.no_grad():
+            y_inner_k = mamba_inner_tok(xzd, cw, cb, xw, dw, A, D, db, perm=p32, out_rows=p32)
+    finally:
+        ssi.DT_PROJ_IN_SPLIT = True
+    assert _lib.last_kernel() == "scan_tok2_n16" and rel_err(N(y_inner_k), N(y)) < 1e-4          # (the round-5 composition: dt_proj kernel + split)
     for b, slab in ((0, 3), (3, 16)):
         sl = slice(slab * 64, slab * 64 + 64)
         xz_b = xz[b].float().numpy()
@@ -497,6 +507,11 @@ def test_config4_l16384_conv_scan_carries():
         err = rel_err(N(y[b, :, sl]), ref)
         print(f"config 4 scan (split mode) vs oracle, sample {b} slab {slab}: {err:.3e}")
         assert err < 1e-3, err
+        # ... and the model's op (delta formed in the split's first pass) against the oracle on ITS OWN stage values: fp32 dt_proj + softplus, rounded once
+        ref_in = _oracle_slab(xz_b, u_ref, xdbl_ref, delta_ref, w, perm, perm, sl, R, Nst)
+        err_in = rel_err(N(y_inner[b, :, sl]), ref_in)
+        print(f"config 4 mamba_inner_tok (dt_proj inside the split's first pass) vs oracle, sample {b} slab {slab}: {err_in:.3e}")
+        assert err_in < 2e-3, err_in
         # carries: h and the decay product at the end of every 2048-step chunk, float64 recurrence on the same operands
         Aa = w["A"][sl].astype(np.float64)                          # (64, N)
         h = np.zeros((64, Nst))

@@ -541,11 +541,11 @@ def test_scan_tok2_dt_proj_in_kernel_preactivated_gate(Bsz, L, Di, R):
 
 
 @pytest.mark.parametrize("io", ["bf16", "f16"])
-@pytest.mark.parametrize("Bsz,L,Di,R,use_perm", [(3, 1024, 192, 40, True), (2, 256, 64, 48, False), (22, 64, 64 * 70, 48, True)])
+@pytest.mark.parametrize("Bsz,L,Di,R,use_perm", [(70, 64, 192, 40, True), (8, 256, 64 * 26, 48, False), (24, 64, 4096, 48, True)])      # (> 200 workgroups: no sequence split; 24 x 64 = 1536: one round of six per CU)
 def test_scan_tok2_accumulating_form(Bsz, L, Di, R, use_perm, io, monkeypatch):
     """ZIGMA_SCAN_ACCUMULATE (round 6): mamba_inner_tok(add_to=y0) — the second sweep of `v2` adding itself to the first one's result in the scan's
     epilogue (reference mamba_simple.py:335-339: out + out_b.flip) — against y0 + mamba_inner_tok(...) evaluated in fp32 on the separate results, on the
-    five- and the six-resident form (22 x 70 = 1540 workgroups) of the kernel; the in-place fallback (knob off) gives the rounded-twice sum."""
+    five- and the six-resident form (24 x 64 = 1536 workgroups) of the kernel; the in-place fallback (knob off) gives the rounded-twice sum."""
     import zigma_amd.selective_scan_interface as ssi
     from zigma_amd import _lib
     dtype = torch.bfloat16 if io == "bf16" else torch.float16
@@ -570,7 +570,7 @@ def test_scan_tok2_accumulating_form(Bsz, L, Di, R, use_perm, io, monkeypatch):
         got2 = ssi.mamba_inner_tok(xz, cw, cb, xw, dw, A, D, db, perm=perm, add_to=acc2)
     assert got is acc and got2 is acc2
     assert k_plain.startswith("scan_tok2_n16_dtproj") and k_acc == k_plain + "_acc", (k_plain, k_acc)
-    assert ("_r6" in k_acc) == (Bsz * (Di // 64) > 1280)
+    assert ("_r6" in k_acc) == (Bsz * (Di // 64) == 1536)
     ref = y0.float() + y.float()                       # y is the rounded result of the plain call: the accumulating form adds the UNROUNDED one
     ulp = 2.0 ** (-8 if io == "bf16" else -11)
     err = (got.float() - ref).abs()

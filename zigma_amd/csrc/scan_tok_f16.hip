@@ -8,7 +8,7 @@ int launch_scan_tok_f16(const zigma_scan_params_t &p, hipStream_t stream) {
     return launch_tok_io<F16>(p, stream);
 }
 int launch_scan_tok_f16_dtp(const zigma_scan_params_t &p, hipStream_t stream) {        // p.dt_x set: no other kernel serves it
-    if (!tok2_dtp_ok(p) || (p.flags & ZIGMA_SCAN_PROBE_V1)) return ZIGMA_ERR_UNSUPPORTED;
+    if (!(p.x ? tok2_dtp_split_ok(p) : tok2_dtp_ok(p)) || (p.flags & ZIGMA_SCAN_PROBE_V1)) return ZIGMA_ERR_UNSUPPORTED;
     return launch_tok2<F16>(p, stream);
 }
 }  // namespace zigma

@@ -194,8 +194,12 @@ extern "C" int zigma_selective_scan_fwd(const zigma_scan_params_t *pp, void *str
     if (p.dt_x) {       // ABI 9: dt_proj inside the token-major hot kernel; `delta` is not read (the layout checks below see u's strides)
         if (!p.u || !p.dt_w || !p.A || !p.B || !p.C || !p.z || !p.out_z) return ZIGMA_ERR_NULL;
         zigma_scan_params_t q = p;
-        q.delta = p.u;
-        q.delta_batch_stride = p.u_batch_stride; q.delta_d_stride = p.u_d_stride; q.delta_l_stride = p.u_l_stride;
+        if (p.x) {      // sequence split (ABI 10): `delta` is a WORKSPACE of u's shape the first pass fills with softplus(dt_proj + bias) for the second
+            if (!p.delta || p.reset_period != 0) return p.delta ? ZIGMA_ERR_SHAPE : ZIGMA_ERR_NULL;
+        } else {
+            q.delta = p.u;
+            q.delta_batch_stride = p.u_batch_stride; q.delta_d_stride = p.u_d_stride; q.delta_l_stride = p.u_l_stride;
+        }
         if ((p.io_dtype != ZIGMA_BF16 && p.io_dtype != ZIGMA_F16) || !tok_eligible(q) || p.batch > 65535) return ZIGMA_ERR_UNSUPPORTED;
         return p.io_dtype == ZIGMA_BF16 ? launch_scan_tok_bf16_dtp(q, stream) : launch_scan_tok_f16_dtp(q, stream);
     }

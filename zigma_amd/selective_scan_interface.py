@@ -73,13 +73,17 @@ def scan_raw(u, delta, A, B, C, D=None, z=None, delta_bias=None, delta_softplus=
     info: optional list; receives [kernel family (_lib.SCAN_KERNEL_*), 1 if `checkpoints` is being written].
     dt_x, dt_w (ABI 9, with delta=None): dt_proj + bias + softplus inside the token-major hot kernel — dt_x (batch, seqlen, >= dt_rank)
     bf16 rows in SCAN order (x_dbl as x_proj wrote it), dt_w (dim, dt_rank); delta' = softplus(dt_x[..., :dt_rank] @ dt_w.T + delta_bias).
+    dt_x, dt_w AND delta AND x (ABI 10): the sequence split with dt_proj inside its first pass — delta (uninitialised, shape of u) receives the step sizes.
     accumulate (with dt_x / dt_w only): out_z += y * silu(z) — the second sweep of `v2` adds itself to the first one's result (ZIGMA_SCAN_ACCUMULATE)."""
     dev = _lib.require_device(u, delta, A, B, C, D, z, delta_bias, out, out_z, x, z_row_index, out_row_index, dt_x, dt_w)
     if delta is None:
         if dt_x is None or dt_w is None or not delta_softplus:
             raise RuntimeError("delta=None needs dt_x, dt_w and delta_softplus=True")
     elif dt_x is not None or dt_w is not None:
-        raise RuntimeError("pass either delta or (dt_x, dt_w)")
+        # (ABI 10) with the carry tensor x — the sequence split — delta is a WORKSPACE: the first pass forms softplus(dt_proj + bias) itself and
+        # writes it there for the second pass; without x the two are alternatives
+        if x is None or dt_x is None or dt_w is None or not delta_softplus:
+            raise RuntimeError("pass either delta or (dt_x, dt_w); both only with x (sequence split: delta is the workspace the first pass fills)")
     if u.dim() != 3 or (delta is not None and delta.shape != u.shape):
         raise RuntimeError("u and delta must both be (batch, dim, seqlen)")
     if A.is_complex():
@@ -254,6 +258,7 @@ def conv_x_proj(x_half, conv_w, conv_b, x_proj_weight, perm=None, _flags=0):
 
 
 ACCUMULATE_IN_SCAN = True     # `v2`: the second sweep's add in its scan epilogue (False: the in-place add; A/B in tests / tools)
+DT_PROJ_IN_SPLIT = True       # sequence-split mode: dt_proj + softplus inside the split's first pass, which writes delta for the second (round 6)
 DT_PROJ_IN_SCAN = True     # dt_proj + softplus in the scan's tile prologue (MFMA) instead of a kernel of its own
 
 
@@ -605,8 +610,14 @@ def _inner_tok_tail(u, x_dbl, z_half, delta_proj_weight, A, D, delta_bias, perm,
     in_scan = (DT_PROJ_IN_SCAN and delta_softplus
                and dt_in_scan_eligible(u, x_dbl, delta_proj_weight, reset_period, out if add_to is None else add_to, dstate=N, z=z_half)
                and B_proj_bias is None and C_proj_bias is None and not split_chunk_len(Bsz, Di, L, reset_period))
+    chunk_len_split = split_chunk_len(Bsz, Di, L, reset_period)
+    in_split = (DT_PROJ_IN_SPLIT and not in_scan and chunk_len_split and delta_softplus and B_proj_bias is None and C_proj_bias is None and delta_bias is not None
+                and not z_preactivated and u.dtype == z_half.dtype and dt_in_scan_eligible(u, x_dbl, delta_proj_weight, reset_period, out if add_to is None else add_to, dstate=N, z=z_half)
+                and Bsz * (Di // 64) < 768 and chunk_len_split % 16 == 0 and -(-L // chunk_len_split) >= 2)
     if in_scan:                      # dt_proj + bias + softplus inside the scan kernel's tile prologue: delta is never materialised
         delta = None
+    elif in_split:                   # sequence split: the first pass forms delta and writes it into this workspace for the second (no dt_proj kernel)
+        delta = torch.empty(Bsz, L, Di, device=u.device, dtype=u.dtype)
     elif delta_softplus and dt_proj_eligible(x_dbl, R, delta_proj_weight):   # K = dt_rank GEMM + bias + softplus in one write-bound MFMA kernel; scan skips its softplus
         delta = dt_proj_softplus(x_dbl, R, delta_proj_weight, delta_bias, True)
         delta_bias, delta_softplus = None, False
@@ -626,9 +637,10 @@ def _inner_tok_tail(u, x_dbl, z_half, delta_proj_weight, A, D, delta_bias, perm,
         xc = torch.empty(Bsz, Di, -(-L // chunk_len), 2 * N, device=u.device, dtype=torch.float32)
     else:
         chunk_len = 2048
+    dt_inside = in_scan or in_split
     scan_raw(u.transpose(1, 2), None if in_scan else delta.transpose(1, 2), A, Bm.transpose(1, 2).unsqueeze(1),
              Cm.transpose(1, 2).unsqueeze(1), D, z_half.transpose(1, 2), delta_bias, delta_softplus,
              out_z=y.transpose(1, 2), z_row_index=perm, out_row_index=perm if out_rows is None else out_rows,
              want_out=False, x=xc, reset_period=reset_period, chunk_len=chunk_len, z_preactivated=z_preactivated,
-             dt_x=x_dbl if in_scan else None, dt_w=delta_proj_weight if in_scan else None, accumulate=acc)
+             dt_x=x_dbl if dt_inside else None, dt_w=delta_proj_weight if dt_inside else None, accumulate=acc)
     return y if (add_to is None or acc) else add_to.add_(y)
