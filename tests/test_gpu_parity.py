@@ -580,6 +580,40 @@ def test_scan_tok2_accumulating_form(Bsz, L, Di, R, use_perm, io, monkeypatch):
     assert rel_err(N(got), N(got2)) < (4e-3 if io == "bf16" else 6e-4)
 
 
+@pytest.mark.parametrize("io", ["bf16", "f16"])
+@pytest.mark.parametrize("T,nseq,K", [(16, 2, 40), (32, 3, 12), (16, 4, 256)])
+def test_dt_proj_in_kernel_with_reset_period(T, nseq, K, io, monkeypatch):
+    """The video temporal layers (batch = k pixels, sequence = (b, t) on strided views, conv window and SSM state restarting every T steps) with dt_proj +
+    softplus inside the scan kernel (round 6): against the same call on the dt_proj kernel + scan, and against the sequences run as separate batch rows."""
+    import zigma_amd.selective_scan_interface as ssi
+    from zigma_amd import _lib
+    dtype = torch.bfloat16 if io == "bf16" else torch.float16
+    g = torch.Generator().manual_seed(T * nseq + K)
+    Di, R, Nst = 128, 40, 16
+    mk = lambda *s, sc=1.0: (torch.randn(*s, generator=g) * sc).to(DEV, dtype)
+    full = mk(nseq * T, K, 2 * Di)                                  # tokens (b t, k) — the model's (b, (t k), c) layout
+    xz = full.transpose(0, 1)                                       # (k, b t, c): a strided view, as Mamba passes it
+    cw, cb, xw, dw = mk(Di, 1, 4, sc=0.5), mk(Di, sc=0.1), mk(R + 2 * Nst, Di, sc=Di ** -0.5), mk(Di, R, sc=R ** -0.5)
+    A = -torch.exp(0.5 * torch.randn(Di, Nst, generator=g)).to(DEV)
+    D, db = torch.randn(Di, generator=g).to(DEV), (torch.randn(Di, generator=g) - 2).to(DEV)
+    base = (torch.arange(nseq, dtype=torch.int32) * T).repeat_interleave(T)
+    perm = (base + torch.randperm(T, generator=g).to(torch.int32).repeat(nseq)).to(DEV)
+    with torch.no_grad():
+        y_in = ssi.mamba_inner_tok(xz, cw, cb, xw, dw, A, D, db, perm=perm, reset_period=T)
+        k_in = _lib.last_kernel()
+        monkeypatch.setattr(ssi, "DT_PROJ_IN_SCAN", False)
+        y_k = ssi.mamba_inner_tok(xz, cw, cb, xw, dw, A, D, db, perm=perm, reset_period=T)
+        k_k = _lib.last_kernel()
+        monkeypatch.setattr(ssi, "DT_PROJ_IN_SCAN", True)
+        sep = full.view(nseq, T, K, 2 * Di).permute(2, 0, 1, 3).reshape(K * nseq, T, 2 * Di).contiguous()      # (k b, t, c): every sequence its own row
+        y_sep = ssi.mamba_inner_tok(sep, cw, cb, xw, dw, A, D, db, perm=perm[:T])
+    assert k_in == "scan_tok2_n16_dtproj" and k_k == "scan_tok2_n16", (k_in, k_k)
+    tol = 6e-3 if io == "bf16" else 1e-3                            # (the kernel path rounds delta to the I/O type, the in-kernel one does not)
+    assert rel_err(N(y_in), N(y_k)) < tol, rel_err(N(y_in), N(y_k))
+    assert rel_err(N(y_in), N(y_sep.view(K, nseq * T, Di))) < tol
+    assert torch.isfinite(y_in).all()
+
+
 def test_scan_dt_in_kernel_limits():
     """What the in-kernel dt_proj (zigma_scan_params_t.dt_x) refuses — the limits tok2_dtp_ok() states, each hit on its own: with dt_x
     set no other kernel serves the call, so the C side answers ZIGMA_ERR_UNSUPPORTED and the caller has to keep the dt_proj kernel."""
@@ -601,9 +635,10 @@ def test_scan_dt_in_kernel_limits():
     with pytest.raises(RuntimeError):       # dt_rank % 8 != 0 (36 columns of the 40-wide rows)
         ok(dt_w=wt[:, :36])
     assert not dt_in_scan_eligible(ut, xt, wt[:, :36], dstate=Nst)
-    with pytest.raises(RuntimeError):       # reset_period (the video temporal layers keep the dt_proj kernel)
-        ok(reset_period=16)
-    assert not dt_in_scan_eligible(ut, xt, wt, reset_period=16, dstate=Nst)
+    ok(reset_period=16)                     # (round 6: the video temporal layers are served too — test_dt_proj_in_kernel_with_reset_period)
+    assert dt_in_scan_eligible(ut, xt, wt, reset_period=16, dstate=Nst) and not dt_in_scan_eligible(ut, xt, wt, reset_period=8, dstate=Nst)
+    with pytest.raises(RuntimeError):       # a reset period that is not whole tiles
+        ok(reset_period=8)
     with pytest.raises(RuntimeError):       # a carry buffer (sequence split) together with dt_x
         ok(x=torch.empty(Bsz, Di, 2, 2 * Nst, device=DEV), chunk_len=16)
     with pytest.raises(RuntimeError):       # the training form (ungated out) together with dt_x

@@ -193,6 +193,7 @@ extern "C" int zigma_selective_scan_fwd(const zigma_scan_params_t *pp, void *str
     if (p.batch == 0 || p.dim == 0 || p.seqlen == 0) return ZIGMA_OK;  // empty (pointers may be NULL): nothing to launch
     if (p.dt_x) {       // ABI 9: dt_proj inside the token-major hot kernel; `delta` is not read (the layout checks below see u's strides)
         if (!p.u || !p.dt_w || !p.A || !p.B || !p.C || !p.z || !p.out_z) return ZIGMA_ERR_NULL;
+        if (p.reset_period < 0 || p.reset_period % 16 != 0) return ZIGMA_ERR_SHAPE;
         zigma_scan_params_t q = p;
         if (p.x) {      // sequence split (ABI 10): `delta` is a WORKSPACE of u's shape the first pass fills with softplus(dt_proj + bias) for the second
             if (!p.delta || p.reset_period != 0) return p.delta ? ZIGMA_ERR_SHAPE : ZIGMA_ERR_NULL;

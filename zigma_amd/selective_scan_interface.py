@@ -268,12 +268,12 @@ _knobs.apply(globals(), "selective_scan_interface")      # (SPLIT_MAX_WGS, CONV_
 
 def dt_in_scan_eligible(u, x_dbl, weight, reset_period=0, out=None, dstate=16, z=None):
     """limits of the in-kernel dt_proj of scan_tok2_kernel (zigma_scan_params_t.dt_x), mirroring tok2_dtp_ok() / tok2_layout_ok() /
-    tok_eligible() of csrc/: bf16 / fp16, whole-sequence mode of the hot kernel (dstate == 16, seqlen % 16 == 0, d_inner % 64 == 0, no
-    reset_period), 32 <= dt_rank <= 64 and % 8 == 0, x_dbl rows >= 64 wide on 16-byte boundaries, channel-contiguous u / z, and every
+    tok_eligible() of csrc/: bf16 / fp16, whole-sequence mode of the hot kernel (dstate == 16, seqlen % 16 == 0, d_inner % 64 == 0; reset_period a
+    multiple of 16 — the video temporal layers, round 6), 32 <= dt_rank <= 64 and % 8 == 0, x_dbl rows >= 64 wide on 16-byte boundaries, channel-contiguous u / z, and every
     in-sample offset (seqlen * row stride, in bytes of up to 4-byte elements) below 2^31 / 4.  A caller that gets False keeps the
     dt_proj kernel (or F.linear) + the ordinary scan call, which serves every shape the reference does."""
     R = weight.shape[1]
-    if not (u.is_cuda and u.dtype in (torch.bfloat16, torch.float16) and x_dbl.dtype == u.dtype and weight.dtype == u.dtype and not reset_period
+    if not (u.is_cuda and u.dtype in (torch.bfloat16, torch.float16) and x_dbl.dtype == u.dtype and weight.dtype == u.dtype and reset_period >= 0 and reset_period % 16 == 0
             and dstate == 16 and u.dim() == 3 and x_dbl.dim() == 3
             and 32 <= R <= 64 and R % 8 == 0 and u.shape[1] % 16 == 0 and u.shape[2] % 64 == 0 and x_dbl.shape[2] >= 64 and x_dbl.shape[2] >= R + 2 * dstate
             and u.stride(2) == 1 and x_dbl.stride(2) == 1 and x_dbl.stride(1) % 8 == 0 and x_dbl.stride(0) % 8 == 0 and x_dbl.stride(1) >= 64
