@@ -114,11 +114,12 @@ def test_no_routing_environment_switches():
 # The cells of the sweep below that run on the LIBRARY (F.linear = hipBLASLt), reviewed one by one.  Everything else of
 # E x tokens x role runs on an own kernel.  Why each group is here:
 #   in_proj, every E, 4096 tokens           below 8192 tokens the library ties or beats every own form (tools/linear_ws_probe.py: a tie at 4096)
-#   in_proj, E = 1024, 8192 tokens          k = 1024 is not a weight-stationary width and 32 x 16 tiles... 8192 / 256 x 16 = 512 tiles: see below (NOT library)
-#   out_proj, E = 512 / 1024, 16 384 tokens  k = 1024 / 2048 are not 128-feature-panel widths; E = 512: 64 x 2 = 128 tiles is below the 4-wave kernel's floor
+#   out_proj, E = 512, 16 384 tokens        k = 1024 is not a 128-feature-panel width and 64 x 2 = 128 tiles is below the 4-wave kernel's floor (E = 1024: 256 tiles, own)
+#   in_proj, E = 768, >= 65 536 tokens      measured: the library is the faster kernel there (routing.py row in_proj.library_k768)
 ROUTING_LIBRARY_CELLS = {
     ("in_proj", 512, 4096), ("in_proj", 640, 4096), ("in_proj", 768, 4096), ("in_proj", 1024, 4096),
     ("out_proj", 512, 16384),
+    ("in_proj", 768, 65536), ("in_proj", 768, 131072),      # E = 768 from 65 536 tokens on: hipBLASLt is 3 % faster inside config 3y's forward than the 4-wave kernel (round 6 A/B)
 }
 
 
@@ -139,11 +140,11 @@ def test_routing_table():
                     lib_cells.add((role, E, tokens))
     assert lib_cells == ROUTING_LIBRARY_CELLS, (lib_cells - ROUTING_LIBRARY_CELLS, ROUTING_LIBRARY_CELLS - lib_cells)
     # (iii) the README model at B = 64 and the shipped yamls' E = 768 at B = 64 / 8
-    assert zr.route("in_proj", 65536, 2560, 640).row == "in_proj.ws" and zr.route("in_proj", 65536, 3072, 768).row == "in_proj.tiled_wide_k"
+    assert zr.route("in_proj", 65536, 2560, 640).row == "in_proj.ws" and zr.route("in_proj", 65536, 3072, 768).row == "in_proj.library_k768" and zr.route("in_proj", 32768, 3072, 768).row == "in_proj.tiled_wide_k"
     assert zr.route("out_proj", 65536, 640, 1280) == zr.Route("tiled", True, "out_proj.tiled") and zr.route("out_proj", 16384, 640, 1280).row == "out_proj.ws128"
     assert zr.route("out_proj", 8192, 768, 1536).row == "out_proj.sm" and zr.route("to_q", 8192, 512, 640).row == "to_q.sm"
     assert zr.route("to_out", 65536, 640, 512) == zr.Route("tiled", True, "to_out.tiled") and zr.route("to_q", 65536, 512, 640).row == "to_q.tiled"
-    assert zr.kernel_name(zr.route("in_proj", 65536, 3072, 768), 65536, 3072, 768) == "linear4w_256x256"
+    assert zr.kernel_name(zr.route("in_proj", 32768, 3072, 768), 32768, 3072, 768) == "linear4w_256x256"
     assert zr.kernel_name(zr.route("to_q", 16384, 512, 640), 16384, 512, 640) == "linear_tn_"
     # the 128-feature-panel form holds at most 32 panels — in_proj of an E = 1280 / 1536 model must not be claimed for it
     assert not zr.serves_ws(16384, 5120, 1280) and not zr.serves_ws(16384, 6144, 1536) and zr.serves_ws(16384, 4096, 1280)

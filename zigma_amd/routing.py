@@ -87,6 +87,10 @@ TABLE = (
     Row("in_proj.ws", "in_proj", {512, 640}, (1024, 8192), (8192, INF), "ws", False,
         "W_in panels resident in registers, only tokens stream: 33.5 / 52 / 93 / 186 us at 8192 ... 65 536 tokens against 41.5 / 72 / 106 / 200 (library), "
         "profiles/r04_g_linear_ws_probe.jsonl, r05_e_bench_kernel_stats.csv"),
+    Row("in_proj.library_k768", "in_proj", {768}, (2048, INF), (65536, INF), "library", False,
+        "E = 768 at >= 65 536 tokens: hipBLASLt 262-270 us against 276-303 for the 4-wave kernel (weights of k = 768 do not fit the weight-stationary form: 384 registers per "
+        "lane); inside config 3y's forward 23.44-23.55 ms per evaluation with the library against 24.16-24.27 (one launch) / 24.16-24.19 (halves): -3.0 %, round 6 A/B on one box "
+        "(DESIGN.md §0).  A plain GEMM without epilogue: the one place the library is the faster kernel"),
     Row("in_proj.tiled_wide_k", "in_proj", (704, INF), (2048, INF), (8192, INF), "tiled", False,
         "E = 768 (every shipped yaml): ONE launch of the 4-wave kernel, 49 / 71 / 139 / 268 us against 60 / 72 / 137 / 263 (library) and 58 / 93 / 141 / 275 as halves, "
         "profiles/r05_b_shapes_probe.jsonl; needs serves_4w (checked below)"),
