@@ -531,7 +531,9 @@ def main():
                         dt_proj_inside=bool(dt_in), limiter="valu", valu_floor_us=valu_floor_us,
                         valu_frac=valu_floor_us / (ms * 1e3), valu_floor_measured_rates_us=valu_floor_measured_us,
                         valu_frac_measured_rates=valu_floor_measured_us / (ms * 1e3),
-                        valu_rates_source="profiles/valu_rates_gfx950.json <- profiles/r02_ubench2_valu_rates.txt (tools/ubench2: ns per wave-instruction per SIMD)")
+                        valu_rates_source="profiles/valu_rates_gfx950.json <- profiles/r02_ubench2_valu_rates.txt (tools/ubench2: ns per wave-instruction per SIMD)",
+                        idle_accounting="profiles/r06_c_scan_idle_probe_b64.json (tools/scan_idle_probe.py, same instruction stream with its waits removed one by one): "
+                                        "VALU stream alone 224-229 us; + row loads 237-241; + LDS operand reads / y hand-over / barriers = the kernel, 255-264 us stand-alone")
         line = dict(metric="denoiser-forward latents/sec (BxL tokens/s), ZigMa d=640 L=32^2",
                     value=world * batch * L * args.steps / elapsed, unit="tokens/s", n_gpus=world, steps=args.steps,
                     warmup=args.warmup, ms_per_step=elapsed / args.steps * 1e3, higher_is_better=True, scaling="weak",
