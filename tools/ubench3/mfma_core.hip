@@ -8,6 +8,11 @@
 //   8: form 7 from a 16-bit table (2 x s_load_dwordx2 + 8 SALU conversions per step): the deployable form
 //   10 / 11: forms 7 / 8 with the hand-over of form 0 (one 4-byte write per step)
 //   9: functional probe of the 4x4x1 operand / result layout
+//   12 (round 6): the BARRIER-FREE decomposition — a wave = 16 channels x 4 state-quads (lane = (row r, quad q, j): channel 4 r + j, states
+//       4 q .. 4 q + 3), y reduced across the four lanes of a channel by two DPP adds per step (row_ror:8, row_ror:4), the second one bank-masked so that
+//       lane q keeps the steps s = q mod 4 (the per-element work stays 4 elements per lane); no s_y hand-over, no workgroup barrier
+//   13: form 4 (y summed in registers) without the barriers = what form 0 would cost with no hand-over and no synchronisation at all
+//   14: form 12 with the hazard no-ops of its DPP adds left to luck (NOT valid code: a lower bound of what scheduling them away could reach)
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 typedef float v2f __attribute__((ext_vector_type(2)));
@@ -32,6 +37,41 @@ __global__ __launch_bounds__(256, 5) void core(float *__restrict__ out, const fl
         s_dtdu[i >> 6][i & 63][1] = in[(i * 3 + 1) & 1023] - 0.5f;
     }
     for (int i = tid; i < 512; i += 256) s_bc[i >> 5][(i >> 4) & 1][i & 15] = in[(i + 17) & 1023] - 0.5f;
+    if constexpr (MODE == 12 || MODE == 14) {
+        const int q = (lane >> 2) & 3, ch = wave * 16 + 4 * (lane >> 4) + (lane & 3), nq = q * 4;
+        v2f a2A = {-1.f - in[ch + nq], -2.f - in[ch + nq + 64]}, a2B = {-3.f - in[ch + nq + 128], -4.f - in[ch + nq + 192]};
+        v2f hA = {0.f, 0.f}, hB = {0.f, 0.f};
+        float acc = 0.f;
+        __syncthreads();
+#pragma unroll 1
+        for (int t = 0; t < tiles; ++t) {
+            float keep[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int s = 0; s < 16; ++s) {
+                const v2f dc = *reinterpret_cast<const v2f *>(&s_dtdu[s][ch][0]);        // 16 distinct addresses, each read by the 4 lanes of a channel
+                const v4f Bc = *reinterpret_cast<const v4f *>(&s_bc[s][0][nq]);          // 4 distinct addresses
+                const v4f Cc = *reinterpret_cast<const v4f *>(&s_bc[s][1][nq]);
+                const v2f dtv = {dc.x, dc.x}, duv = {dc.y, dc.y};
+                const v2f dA = a2A * dtv, dB = a2B * dtv;
+                const v2f eA = {ex2(dA.x), ex2(dA.y)}, eB = {ex2(dB.x), ex2(dB.y)};
+                const v2f bA = v2f{Bc.x, Bc.y} * duv, bB = v2f{Bc.z, Bc.w} * duv;
+                hA = __builtin_elementwise_fma(eA, hA, bA);
+                hB = __builtin_elementwise_fma(eB, hB, bB);
+                const float y = __builtin_fmaf(Cc.w, hB.y, __builtin_fmaf(Cc.z, hB.x, __builtin_fmaf(Cc.y, hA.y, Cc.x * hA.x)));
+                float y1;
+                if constexpr (MODE == 12) {      // (VALU write -> DPP read of the same register: 2 wait states, which the compiler cannot see inside the asm)
+                    asm("s_nop 1\n\tv_add_f32_dpp %0, %1, %1 row_ror:8 row_mask:0xf bank_mask:0xf" : "=v"(y1) : "v"(y));
+                    asm("s_nop 1\n\tv_add_f32_dpp %0, %1, %1 row_ror:4 row_mask:0xf bank_mask:%2" : "+v"(keep[s >> 2]) : "v"(y1), "n"(1 << (s & 3)));
+                } else {
+                    asm("v_add_f32_dpp %0, %1, %1 row_ror:8 row_mask:0xf bank_mask:0xf" : "=v"(y1) : "v"(y));
+                    asm("v_add_f32_dpp %0, %1, %1 row_ror:4 row_mask:0xf bank_mask:%2" : "+v"(keep[s >> 2]) : "v"(y1), "n"(1 << (s & 3)));
+                }
+            }
+            acc += keep[0] + keep[1] + keep[2] + keep[3];
+        }
+        out[blockIdx.x * 256 + tid] = acc + hA.x + hA.y + hB.x + hB.y;
+        return;
+    }
     v2f a2A = {-1.f - in[lane], -2.f - in[lane + 64]}, a2B = {-3.f - in[lane + 128], -4.f - in[lane + 192]};
     v2f hA = {0.f, 0.f}, hB = {0.f, 0.f};
     float acc = 0.f;
@@ -46,7 +86,7 @@ __global__ __launch_bounds__(256, 5) void core(float *__restrict__ out, const fl
             const v2f dtv = {dc.x, dc.x}, duv = {dc.y, dc.y};
             const v2f dA = a2A * dtv, dB = a2B * dtv;
             const v2f eA = {ex2(dA.x), ex2(dA.y)}, eB = {ex2(dB.x), ex2(dB.y)};
-            if constexpr (MODE == 0 || MODE == 3 || MODE >= 4) {
+            if constexpr (MODE == 0 || MODE == 3 || MODE >= 4) {      // (12 / 14 returned above)
                 v4f Bc = *reinterpret_cast<const v4f *>(&s_bc[s][0][n0]), Cs = Cc;
                 if constexpr (MODE >= 6) Cs = *reinterpret_cast<const v4f *>(in + ((t & 1) * 512 + s * 32 + 16 + n0));     // wave-uniform address
                 if constexpr (MODE == 7 || MODE == 10) Bc = *reinterpret_cast<const v4f *>(in + ((t & 1) * 512 + s * 32 + n0));
@@ -62,7 +102,7 @@ __global__ __launch_bounds__(256, 5) void core(float *__restrict__ out, const fl
                 if constexpr (MODE != 3) {
                     const float y = __builtin_fmaf(Cs.w, hB.y, __builtin_fmaf(Cs.z, hB.x, __builtin_fmaf(Cs.y, hA.y, Cs.x * hA.x)));
                     if constexpr (MODE == 0 || MODE >= 10) s_y[wave][s][lane] = y;
-                    else if constexpr (MODE == 4) acc += y;
+                    else if constexpr (MODE == 4 || MODE == 13) acc += y;
                     else {
                         yg[s & 3] = y;
                         if ((s & 3) == 3) *reinterpret_cast<v4f *>(&s_y4[wave][s >> 2][lane][0]) = v4f{yg[0], yg[1], yg[2], yg[3]};
@@ -82,7 +122,7 @@ __global__ __launch_bounds__(256, 5) void core(float *__restrict__ out, const fl
                 }
             }
         }
-        __syncthreads();
+        if (MODE != 13) __syncthreads();
         if (MODE >= 5 && MODE <= 8) {
             v4f ys = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -93,7 +133,7 @@ __global__ __launch_bounds__(256, 5) void core(float *__restrict__ out, const fl
 #pragma unroll
             for (int e = 0; e < 4; ++e) acc += s_y[0][wave * 4 + e][lane] + s_y[1][wave * 4 + e][lane] + s_y[2][wave * 4 + e][lane] + s_y[3][wave * 4 + e][lane];
         }
-        __syncthreads();
+        if (MODE != 13) __syncthreads();
     }
     out[blockIdx.x * 256 + tid] = acc + hA.x + hA.y + hB.x + hB.y;
 }
@@ -114,6 +154,9 @@ extern "C" int ubench3_launch(int mode, int blocks, int tiles, float *out, const
         case 10: hipLaunchKernelGGL(core<10>, g, b, 0, st, out, in, tiles); break;
         case 11: hipLaunchKernelGGL(core<11>, g, b, 0, st, out, in, tiles); break;
         case 9: hipLaunchKernelGGL(core<9>, g, b, 0, st, out, in, tiles); break;
+        case 12: hipLaunchKernelGGL(core<12>, g, b, 0, st, out, in, tiles); break;
+        case 13: hipLaunchKernelGGL(core<13>, g, b, 0, st, out, in, tiles); break;
+        case 14: hipLaunchKernelGGL(core<14>, g, b, 0, st, out, in, tiles); break;
         default: return -1;
     }
     return hipGetLastError() == hipSuccess ? 0 : -5;
