@@ -12,6 +12,7 @@
 //       4 q .. 4 q + 3), y reduced across the four lanes of a channel by two DPP adds per step (row_ror:8, row_ror:4), the second one bank-masked so that
 //       lane q keeps the steps s = q mod 4 (the per-element work stays 4 elements per lane); no s_y hand-over, no workgroup barrier
 //   13: form 4 (y summed in registers) without the barriers = what form 0 would cost with no hand-over and no synchronisation at all
+//   15: two waves x 8 states per slab (128-thread workgroups), hand-over and barriers as in form 0      16: form 15 with y summed in registers, no barriers (its floor)
 //   14: form 12 with the hazard no-ops of its DPP adds left to luck (NOT valid code: a lower bound of what scheduling them away could reach)
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -138,6 +139,54 @@ __global__ __launch_bounds__(256, 5) void core(float *__restrict__ out, const fl
     out[blockIdx.x * 256 + tid] = acc + hA.x + hA.y + hB.x + hB.y;
 }
 
+// form 15 (round 6): TWO waves x 8 states per (sample, slab) instead of four x 4 — half the (dt, dt u) reads and half the partial-y hand-over per slab, barriers
+// couple two waves instead of four, 2.5 waves per SIMD with twice the independent chains each.  128-thread workgroups; tiles of 16 steps; hand-over as in form 0.
+template <int MODE>
+__global__ __launch_bounds__(128, 3) void core8(float *__restrict__ out, const float *__restrict__ in, int tiles) {
+    __shared__ __attribute__((aligned(16))) float s_dtdu[16][64][2];
+    __shared__ __attribute__((aligned(16))) float s_bc[16][2][16];
+    __shared__ __attribute__((aligned(16))) float s_y[2][16][64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), n0 = wave * 8;
+    for (int i = tid; i < 16 * 64; i += 128) {
+        s_dtdu[i >> 6][i & 63][0] = 0.01f + 0.2f * in[(i * 7) & 1023];
+        s_dtdu[i >> 6][i & 63][1] = in[(i * 3 + 1) & 1023] - 0.5f;
+    }
+    for (int i = tid; i < 512; i += 128) s_bc[i >> 5][(i >> 4) & 1][i & 15] = in[(i + 17) & 1023] - 0.5f;
+    v2f a2[4], h[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { a2[k] = v2f{-1.f - k - in[lane + 64 * (k & 3)], -1.5f - k - in[lane + 32 * k]}; h[k] = v2f{0.f, 0.f}; }
+    float acc = 0.f;
+    __syncthreads();
+#pragma unroll 1
+    for (int t = 0; t < tiles; ++t) {
+#pragma unroll
+        for (int s = 0; s < 16; ++s) {
+            const v2f dc = *reinterpret_cast<const v2f *>(&s_dtdu[s][lane][0]);
+            const v4f B0 = *reinterpret_cast<const v4f *>(&s_bc[s][0][n0]), B1 = *reinterpret_cast<const v4f *>(&s_bc[s][0][n0 + 4]);
+            const v4f C0 = *reinterpret_cast<const v4f *>(&s_bc[s][1][n0]), C1 = *reinterpret_cast<const v4f *>(&s_bc[s][1][n0 + 4]);
+            const v2f dtv = {dc.x, dc.x}, duv = {dc.y, dc.y};
+            const v2f Bv[4] = {v2f{B0.x, B0.y}, v2f{B0.z, B0.w}, v2f{B1.x, B1.y}, v2f{B1.z, B1.w}};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const v2f dA = a2[k] * dtv;
+                const v2f e = {ex2(dA.x), ex2(dA.y)};
+                h[k] = __builtin_elementwise_fma(e, h[k], Bv[k] * duv);
+            }
+            float y = C0.x * h[0].x;
+            y = __builtin_fmaf(C0.y, h[0].y, y); y = __builtin_fmaf(C0.z, h[1].x, y); y = __builtin_fmaf(C0.w, h[1].y, y);
+            y = __builtin_fmaf(C1.x, h[2].x, y); y = __builtin_fmaf(C1.y, h[2].y, y); y = __builtin_fmaf(C1.z, h[3].x, y); y = __builtin_fmaf(C1.w, h[3].y, y);
+            if constexpr (MODE == 15) s_y[wave][s][lane] = y; else acc += y;
+        }
+        if constexpr (MODE == 15) {
+            __syncthreads();
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc += s_y[0][wave * 8 + e][lane] + s_y[1][wave * 8 + e][lane];
+            __syncthreads();
+        }
+    }
+    out[blockIdx.x * 128 + tid] = acc + h[0].x + h[1].y + h[2].x + h[3].y;
+}
+
 extern "C" int ubench3_launch(int mode, int blocks, int tiles, float *out, const float *in, void *stream) {
     hipStream_t st = static_cast<hipStream_t>(stream);
     dim3 g(blocks), b(256);
@@ -157,6 +206,8 @@ extern "C" int ubench3_launch(int mode, int blocks, int tiles, float *out, const
         case 12: hipLaunchKernelGGL(core<12>, g, b, 0, st, out, in, tiles); break;
         case 13: hipLaunchKernelGGL(core<13>, g, b, 0, st, out, in, tiles); break;
         case 14: hipLaunchKernelGGL(core<14>, g, b, 0, st, out, in, tiles); break;
+        case 15: hipLaunchKernelGGL(core8<15>, g, dim3(128), 0, st, out, in, tiles); break;
+        case 16: hipLaunchKernelGGL(core8<16>, g, dim3(128), 0, st, out, in, tiles); break;
         default: return -1;
     }
     return hipGetLastError() == hipSuccess ? 0 : -5;

@@ -17,7 +17,7 @@ d = out[:256].cpu().view(64, 4)
 ok = all(float(d[l, i]) == float((4 * (l // 4) + i) * (100 + l)) for l in range(64) for i in range(4))
 print("4x4x1 layout D[reg i][lane 4b+j] = A[lane 4b+i] * B[lane 4b+j]:", ok)
 res = {}
-for mode in (0, 1, 2, 3, 4, 5, 6, 7, 8, 10, 11, 12, 13, 14):
+for mode in (0, 1, 2, 3, 4, 5, 6, 7, 8, 10, 11, 12, 13, 14, 15, 16):
     ts = []
     for rep in range(5):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -32,4 +32,5 @@ print(json.dumps(dict(what="scan core replica, 1280 WG x 64 tiles (B=64, Di=1280
                       mfma_core_no_y=res[2], valu_core_no_y=res[3], valu_y_in_registers=res[4], valu_y_b128_per_4_steps=res[5],
                       c_from_scalar_loads=res[6], b_and_c_from_scalar_loads=res[7], b_and_c_from_16bit_scalar_loads=res[8], f32_scalar_loads_and_per_step_handover=res[10],
                       b16_scalar_loads_and_per_step_handover=res[11],
-                      quad_layout_dpp_reduce_no_barriers=res[12], valu_y_in_registers_no_barriers=res[13], quad_layout_without_hazard_nops_INVALID=res[14], checksum_valu=res["sum0"], checksum_mfma=res["sum1"])))
+                      quad_layout_dpp_reduce_no_barriers=res[12], valu_y_in_registers_no_barriers=res[13], quad_layout_without_hazard_nops_INVALID=res[14],
+                      two_waves_x_8_states=res[15], two_waves_x_8_states_no_handover_no_barriers=res[16], checksum_valu=res["sum0"], checksum_mfma=res["sum1"])))
