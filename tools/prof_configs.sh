@@ -22,7 +22,7 @@ if not f:
 shutil.copy(f[0], f"{R}/gpurun_out/r06_cfg_{tag}_kernel_stats.csv")
 rows = list(csv.DictReader(open(f[0])))
 tot = sum(float(r["TotalDurationNs"]) for r in rows)
-lib = [r for r in rows if r["Name"].startswith("Cijk_")]
+lib = [r for r in rows if "Cijk_" in r["Name"]]       # (hipBLASLt kernels: "Cijk_..." and "Custom_Cijk_...")
 print(f"== {tag}: {len(rows)} kernels, library GEMM rows (Cijk_*): {len(lib)}, their share {sum(float(r['TotalDurationNs']) for r in lib) / tot * 100:.1f} %")
 for r in rows[:12]:
     print(f'   {r["Name"][:64]:64s} calls={r["Calls"]:>5s} avg_us={float(r["AverageNs"])/1e3:8.1f} pct={float(r["TotalDurationNs"])/tot*100:5.1f}')
