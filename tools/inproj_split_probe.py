@@ -5,7 +5,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from zigma_amd.linear import linear
 F = torch.nn.functional
 dev, dt = "cuda", torch.bfloat16
-M, K, N = 65536, 640, 2560
+M, K, N = int(os.environ.get("M", 65536)), int(os.environ.get("K", 640)), int(os.environ.get("N", 2560))
 torch.manual_seed(0)
 x = torch.randn(M, K, device=dev, dtype=dt); w = (torch.randn(N, K, device=dev) * K ** -0.5).to(dt)
 out = torch.empty(M, N, device=dev, dtype=dt)
@@ -13,7 +13,8 @@ def split(parts):
     step = N // parts
     for i in range(parts):
         linear(x, w[i * step:(i + 1) * step], out=out[:, i * step:(i + 1) * step])
-variants = {"4w_1": lambda: split(1), "4w_2": lambda: split(2), "4w_5": lambda: split(5), "4w_10": lambda: split(10), "lib": lambda: F.linear(x, w)}
+PARTS = [int(p_) for p_ in os.environ.get("PARTS", "1,2,5,10").split(",")]
+variants = {**{f"4w_{p_}": (lambda p_=p_: split(p_)) for p_ in PARTS}, "lib": lambda: F.linear(x, w)}
 ref = F.linear(x, w)
 ok = {}
 for k_, fn in variants.items():
