@@ -121,6 +121,7 @@ def project(role, x, weight, bias=None, residual=None, gate=None):
               "tiled_halves": lambda: bias is None and x.dim() == 3 and linear_eligible(x, weight[:n // 2])}[kern]()
         if not ok:
             routing.REFUSED.append((role, tokens, n, k, kern))
+            del routing.REFUSED[:-64]
             kern = "library"
     fuse = residual is not None and r.fuse_add and kern in ("sm", "tiled") and not torch.is_grad_enabled() and gated_residual_eligible(x, residual, gate)
     if kern == "library":

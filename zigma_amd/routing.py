@@ -40,7 +40,7 @@ KERNELS = ("ws", "ws128", "sm", "tiled", "tiled_halves", "library")
 POLICY = "auto"
 DISABLED = ""
 INF = 1 << 40
-REFUSED = []          # (role, tokens, n, k, kernel) of calls a table row chose and the tensor-level check of linear.py turned down
+REFUSED = []          # (role, tokens, n, k, kernel) of calls a table row chose and the tensor-level check of linear.py turned down (the last 64 of them)
 
 
 # ---- shape limits of the kernel families (C side mirrored) ---------------------------------------------------------------------------------

@@ -18,19 +18,29 @@ SPLIT_WGRAD = True        # False: one GEMM (A/B in tools/train_probe.py)
 OWN_TRAIN_GEMMS = True
 
 
-def _bmm_takes_out_dtype():
-    """does this torch's bmm accept out_dtype (fp32 results from 16-bit operands)?  Probed ONCE, on the signature error only — a
-    catch-all around the real call would also swallow an out-of-memory error and silently retry at lower precision."""
-    try:
-        torch.bmm(torch.zeros(1, 1, 1, dtype=torch.bfloat16), torch.zeros(1, 1, 1, dtype=torch.bfloat16), out_dtype=torch.float32)
-        return True
-    except TypeError:
-        return False
-    except RuntimeError:        # (the argument exists; this build has no CPU kernel for it)
-        return True
+_BMM_OUT_DTYPE = {}      # (device type, index, dtype) -> bool
 
 
-_BMM_OUT_DTYPE = _bmm_takes_out_dtype()
+def _bmm_takes_out_dtype(x):
+    """does torch.bmm accept out_dtype=float32 for x's dtype ON x's device?  Probed lazily, once per (device, dtype), with a 1 x 1 x 1 product there (an
+    import-time probe on the CPU says nothing about the GPU backend).  Only the two answers that mean "no" are caught — a missing keyword (TypeError) and a
+    backend that declines the combination (RuntimeError naming it); anything else (e.g. out of memory) propagates."""
+    key = (x.device.type, x.device.index, x.dtype)
+    hit = _BMM_OUT_DTYPE.get(key)
+    if hit is None:
+        a = torch.zeros(1, 1, 1, device=x.device, dtype=x.dtype)
+        try:
+            torch.bmm(a, a, out_dtype=torch.float32)
+            hit = True
+        except TypeError:
+            hit = False
+        except RuntimeError as e:
+            msg = str(e).lower()
+            if not any(w in msg for w in ("out_dtype", "not implemented", "not supported", "unsupported", "expected")):
+                raise
+            hit = False
+        _BMM_OUT_DTYPE[key] = hit
+    return hit
 
 
 def _own_linear(x, weight, bias=None, transposed=False):
@@ -96,7 +106,7 @@ def wgrad(dy2, x2):
     dy3 = dy2.reshape(s, m // s, n)
     x3 = x2.reshape(s, m // s, k)
     # fp32 slab partials (one rounding at the end, like the single GEMM of the reference; a 16-bit partial could also overflow in fp16)
-    if _BMM_OUT_DTYPE:
+    if _bmm_takes_out_dtype(dy2):
         part = torch.bmm(dy3.transpose(1, 2), x3, out_dtype=torch.float32)
     else:                                  # (a torch without out_dtype on bmm)
         part = torch.bmm(dy3.transpose(1, 2), x3).float()
