@@ -2,7 +2,7 @@
 5120, against the library on the 4928 rows.  Measured: 138.3 vs 133.4 us, bit-identical -> the library keeps this one."""
 import os, sys, torch, json
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-os.environ["ZIGMA_LINEAR"] = "all"
+# (linear() carries no policy; routing lives in zigma_amd/routing.py)
 from zigma_amd.linear import linear
 from zigma_amd import _lib
 F = torch.nn.functional
