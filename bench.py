@@ -199,11 +199,15 @@ def check_against_reference(model, wl, x, t, y):
     deterministic fill both sides regenerate from the fixture's seed), the reference run's two samples replace batch positions 0 and B-1 of the TIMED
     inputs, and one forward of the timed path — same batch size, same kernels, same routing — is compared with the reference's own outputs for those two
     rows.  Bars as in tests/test_gpu_baseline_shapes.py: no further from the reference's fp32 result than 1.1 x the reference's own bf16 run is, and
-    within 1e-2 of the reference's bf16 result.  (The fill function lives under oracle/ as test infrastructure; it is a weight generator, not the
-    oracle, and runs here outside the timed region, as the checker only.)"""
+    within 1e-2 of the reference's bf16 result.  (The fill function is part of the fixture — tests/golden/param_fill.py, the weights in generator form — and
+    runs here outside the timed region; nothing under oracle/ is imported by this check.)"""
     import ast
     import numpy as np
-    from oracle.param_fill import fill_state
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("zigma_golden_param_fill", os.path.join(ROOT, "tests", "golden", "param_fill.py"))
+    pf = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(pf)
+    fill_state = pf.fill_state
     path = os.path.join(ROOT, "tests", "golden", "r2_readme_b2.npz")
     if not os.path.exists(path) or x.shape[0] < 2:
         return None
